@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- aggregated edges/s of the fused 1+2-hop SpMM (BASELINE.json metric) on N GPUs of one node.
+
+    python bench.py                                  # N=1, products shape (configs[3]), 20 steps
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W       # configs[4]: same graph row-partitioned, strong scaling
+
+One "step" = one pass of the hot path over the whole graph: [all-gather of the row-sharded embedding over
+RCCL when N > 1] + one fused 1+2-hop SpMM launch per rank (GCNLayer.call, reference
+h2gcn/models/_layers.py:78-81).  Inputs are synthetic (h2gcn_amd/synth.py), generated on the device and
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the
+algorithmic-bytes model behind `roofline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
+
+
+def algorithmic_bytes(nnz_list, n_rows_out, d, n_hops):
+    """per edge one column id + one value + one gathered feature row (no-reuse model), per hop
+    one int64 row-pointer sweep, plus one write of Y[n_rows, H, d]."""
+    return sum(z * (4 + 4 + 4 * d) + (n_rows_out + 1) * 8 for z in nnz_list) + n_rows_out * n_hops * d * 4
+
+
+def cpu_baseline(plan_csr, x_full, d, target_seconds=12.0):
+    """Reported baseline (NOT the target): the plain-C oracle port of the reference's CPU arithmetic, 1 thread
+    (TF's CPU SparseTensorDenseMatMul is single-threaded), on a bounded row sample of the SAME operands."""
+    from oracle import gcn_layer as og
+
+    rowptrs = [c[0] for c in plan_csr]
+    n_rows = rowptrs[0].numel() - 1
+    x_cpu = x_full.cpu().numpy()
+
+    def sample(n_take):
+        parts = []
+        edges = 0
+        for rp, ci, va in plan_csr:
+            hi = int(rp[n_take])
+            parts.append((rp[: n_take + 1].cpu().numpy(), ci[:hi].cpu().numpy(), va[:hi].cpu().numpy()))
+            edges += hi
+        return parts, edges
+
+    # calibrate on ~1e6 edges, then size the sample for ~target_seconds
+    avg_deg = sum(int(rp[-1]) for rp in rowptrs) / max(n_rows, 1)
+    n0 = max(1, min(n_rows, int(1e6 / max(avg_deg, 1))))
+    parts, edges = sample(n0)
+    t = time.perf_counter()
+    og.gcn_layer_c(parts, x_cpu)
+    dt = max(time.perf_counter() - t, 1e-6)
+    rate = edges / dt
+    n1 = max(n0, min(n_rows, int(n0 * target_seconds / dt)))
+    parts, edges = sample(n1)
+    t = time.perf_counter()
+    og.gcn_layer_c(parts, x_cpu)
+    dt = time.perf_counter() - t
+    return {
+        "value": edges / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+        "sample": f"rows [0,{n1}) of the same operands: {edges} aggregated edges, d={d}, {dt:.1f} s, "
+                  f"oracle/spmm_oracle.c (plain C, -O2, 1 thread; host has {os.cpu_count()} cores)",
+        "calibration_edges_per_s": rate,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shape", default="products", choices=["products", "arxiv"])
+    ap.add_argument("--d", type=int, default=0, help="feature width (default: the shape's, 128)")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--long-row-threshold", type=int, default=0)
+    ap.add_argument("--rows-per-wave", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit(f"--gpus {a.gpus} needs a torch.distributed.run launch with {a.gpus} ranks")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: h2gcn_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from h2gcn_amd import HopPlan, synth
+    from h2gcn_amd.partition import EmbeddingAllGather, block_bounds
+
+    cfg = synth.SHAPES[a.shape]
+    n, d = cfg["n"], (a.d or cfg["d"])
+    seeds = (synth.SEED_A1, synth.SEED_A2)
+    r0, r1 = block_bounds(n, world, rank)
+    degs = [synth.synth_degrees(n, cfg["nnz_per_hop"], s, n) for s in seeds]
+    csr = [synth.synth_hop_rows(degs[k], n, seeds[k], r0, r1, device) for k in range(2)]
+    torch.cuda.synchronize()
+    plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n,
+                   variant=a.variant, long_row_threshold=a.long_row_threshold, rows_per_wave=a.rows_per_wave)
+    x_local = synth.synth_features(d, synth.SEED_X, r0, r1, device)
+    gatherer = EmbeddingAllGather(n, d, device)
+    y = torch.empty((r1 - r0, 2, d), dtype=torch.float32, device=device)
+    nnz_local = plan.nnz
+    nnz_t = torch.tensor(nnz_local, dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_reduce(nnz_t)
+    nnz_global = [int(v) for v in nnz_t.tolist()]
+
+    def step():
+        x_full = gatherer.gather(x_local)
+        plan.spmm(x_full, out=y)
+
+    for _ in range(a.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        x_full = gatherer.gather(x_local)
+        ev[i][0].record()          # torch's current stream == the stream the kernel is launched on
+        plan.spmm(x_full, out=y)
+        ev[i][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    kt = torch.tensor([kern_ms], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+    kern_ms_max = float(kt.item())
+
+    edges = sum(nnz_global)
+    b_alg = algorithmic_bytes(nnz_local, r1 - r0, d, 2)
+    achieved = b_alg / (kern_ms * 1e-3) / 1e9
+    out = {
+        "metric": "aggregated edges/sec (1+2-hop SpMM)",
+        "value": edges * a.steps / elapsed,
+        "unit": "edges/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[{3 if a.shape == 'products' else 2}]"
+                        + (f"/configs[4] row-partitioned over {world} GPUs" if world > 1 else "")
+                        + f": synthetic CSR |V|={n}, nnz(A1)={nnz_global[0]}, nnz(A2)={nnz_global[1]}, d={d}, "
+                          "row-normalised values 1/deg, 2-hop CSR supplied (not derived)",
+            "n_rows": n, "nnz_per_hop": nnz_global, "d": d,
+            "parallelism": f"row-partition x{world}" + (", RCCL all-gather of X per step" if world > 1 else ""),
+            "kernel_variant": a.variant,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "kernel": "h2gcn::spmm_hops_kernel (fused 1+2-hop)",
+            "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_max,
+            "algorithmic_bytes_per_launch": b_alg,
+        },
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(csr, x_local, d, a.cpu_seconds)
+        except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

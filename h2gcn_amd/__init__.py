@@ -1,0 +1,22 @@
+"""h2gcn_amd -- MI355X-native hop aggregation for H2GCN (the GCNLayer path of GemsLab/H2GCN).
+
+The package is a thin PyTorch-ROCm front end over ``libh2gcn_hip.so`` (hand-written gfx950 HIP behind the
+C ABI of ``include/h2gcn_hip.h``).  It mirrors the reference's operator interface for this one path:
+
+* :class:`h2gcn_amd.layers.GCNLayer` -- ``layer(adjhops, inputs) -> [N, H, d]``
+  (reference ``h2gcn/models/_layers.py:54-81``);
+* :class:`h2gcn_amd.hops.HopPlan` -- the device-resident ``adj_hops`` operand list
+  (reference ``h2gcn/datasets/_dataset.py:559-576``);
+* :mod:`h2gcn_amd.operands` -- host-side construction of the normalised exact-k-hop matrices
+  (reference ``h2gcn/datasets/_dataset.py:102-158``);
+* :mod:`h2gcn_amd.partition` -- row partitioning + RCCL all-gather for 1..8 GPUs (new; the reference is
+  single-device).
+
+There is no CPU fallback: every compute entry point raises if the HIP library or a GPU is missing.
+"""
+
+__version__ = "0.1.0"
+
+from . import _capi  # noqa: F401  (does not load the library until first use)
+from .hops import HopPlan  # noqa: F401
+from .layers import GCNLayer, hop_spmm  # noqa: F401

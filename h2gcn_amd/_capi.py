@@ -1,0 +1,120 @@
+"""ctypes binding of libh2gcn_hip.so -- the C ABI declared in include/h2gcn_hip.h.
+
+Nothing here computes: it loads the in-tree shared library, declares the prototypes, and turns negative
+status codes into Python exceptions carrying ``h2gcn_last_error()``.  If the library is missing the import of
+this module still succeeds (so CPU-only tooling can import the package) but the first call to :func:`lib`
+raises -- the product path never falls back to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+ABI_VERSION = 1
+MAX_HOPS = 8
+
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_HIP = -2
+ERR_OUT_OF_MEMORY = -3
+ERR_BAD_INDEX = -4
+ERR_NO_TRANSPOSE = -5
+ERR_INTERNAL = -6
+
+PLAN_BUILD_TRANSPOSE = 0x1
+PLAN_SKIP_VALIDATION = 0x2
+
+#: every symbol include/h2gcn_hip.h declares (tests check the built library exports all of them)
+EXPORTED_SYMBOLS = (
+    "h2gcn_abi_version",
+    "h2gcn_last_error",
+    "h2gcn_device_count",
+    "h2gcn_plan_create",
+    "h2gcn_plan_destroy",
+    "h2gcn_plan_info",
+    "h2gcn_spmm_hops_f32",
+    "h2gcn_spmm_hops_T_f32",
+)
+
+
+class PlanOpts(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("long_row_threshold", C.c_int32),
+        ("rows_per_wave", C.c_int32),
+        ("variant", C.c_int32),
+        ("reserved", C.c_int32 * 3),
+    ]
+
+
+class H2GCNError(RuntimeError):
+    """A call into libh2gcn_hip.so failed; ``status`` is the negative h2gcn_status."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libh2gcn_hip: {message} (status {status})")
+        self.status = status
+
+
+def library_path() -> Path:
+    override = os.environ.get("H2GCN_HIP_LIBRARY")
+    if override:
+        return Path(override)
+    return Path(__file__).resolve().parent / "csrc" / "libh2gcn_hip.so"
+
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raises if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not path.exists():
+        raise RuntimeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C h2gcn_amd/csrc`.  h2gcn_amd has no CPU fallback."
+        )
+    L = C.CDLL(str(path))
+    L.h2gcn_abi_version.restype = C.c_int
+    L.h2gcn_abi_version.argtypes = []
+    L.h2gcn_last_error.restype = C.c_char_p
+    L.h2gcn_last_error.argtypes = []
+    L.h2gcn_device_count.restype = C.c_int
+    L.h2gcn_device_count.argtypes = []
+    L.h2gcn_plan_create.restype = C.c_int
+    L.h2gcn_plan_create.argtypes = [
+        C.c_int, C.c_int64, C.c_int64,
+        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+        C.POINTER(PlanOpts), C.c_void_p, C.POINTER(C.c_void_p),
+    ]
+    L.h2gcn_plan_destroy.restype = None
+    L.h2gcn_plan_destroy.argtypes = [C.c_void_p]
+    L.h2gcn_plan_info.restype = C.c_int
+    L.h2gcn_plan_info.argtypes = [
+        C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+        C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+    ]
+    L.h2gcn_spmm_hops_f32.restype = C.c_int
+    L.h2gcn_spmm_hops_f32.argtypes = [
+        C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+    ]
+    L.h2gcn_spmm_hops_T_f32.restype = C.c_int
+    L.h2gcn_spmm_hops_T_f32.argtypes = [
+        C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+    ]
+    got = L.h2gcn_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {got}, this front end expects {ABI_VERSION}")
+    _LIB = L
+    return L
+
+
+def check(status: int) -> None:
+    """Raise :class:`H2GCNError` for a negative status."""
+    if status < 0:
+        msg = lib().h2gcn_last_error()
+        raise H2GCNError(status, msg.decode("utf-8", "replace") if msg else "unknown error")

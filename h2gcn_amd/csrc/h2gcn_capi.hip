@@ -1,0 +1,447 @@
+// h2gcn_capi.hip -- host side of libh2gcn_hip.so: plan construction (CSR-adaptive row binning, optional
+// transposed operands, one-time index validation) and the launchers behind the C ABI of include/h2gcn_hip.h.
+//
+// Reference behaviour this file stands in for (nothing is translated -- the reference has no native code):
+//   * plan_create   <-> building `tensors.adj_hops` once per run, h2gcn/datasets/_dataset.py:559-576,528-535
+//   * spmm_hops     <-> GCNLayer.call, h2gcn/models/_layers.py:78-81 (TF SparseTensorDenseMatMul, :74,76)
+//   * spmm_hops_T   <-> its TF-registered gradient wrt the dense operand (h2gcn/models/H2GCN.py:66-74)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "h2gcn_hip.h"
+#include "spmm_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(h2gcn_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return (int)st;
+}
+
+#define H2GCN_HIP_TRY(expr)                                                                          \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return fail(_e == hipErrorOutOfMemory ? H2GCN_ERR_OUT_OF_MEMORY : H2GCN_ERR_HIP,         \
+                        "%s failed: %s", #expr, hipGetErrorString(_e));                              \
+    } while (0)
+
+struct DeviceBuf {
+    void* p = nullptr;
+    ~DeviceBuf() {
+        if (p) (void)hipFree(p);
+    }
+    DeviceBuf() = default;
+    DeviceBuf(DeviceBuf&& o) noexcept : p(o.p) { o.p = nullptr; }
+    DeviceBuf(const DeviceBuf&) = delete;
+    DeviceBuf& operator=(const DeviceBuf&) = delete;
+};
+
+struct HopOperand {  // one CSR, device pointers
+    const int64_t* rowptr = nullptr;
+    const int32_t* colidx = nullptr;
+    const float* vals = nullptr;
+    int64_t nnz = 0;
+    std::vector<int64_t> long_rows;  // rows whose segment has >= long_row_threshold nonzeros, ascending
+};
+
+struct LongList {
+    DeviceBuf dev;
+    int n = 0;
+};
+
+}  // namespace
+
+struct h2gcn_plan {
+    int n_hops = 0;
+    int64_t n_rows = 0, n_cols = 0;
+    int long_threshold = 1024;
+    int rows_per_wave = 4;
+    int variant = 0;
+    bool has_transpose = false;
+    int device = 0;
+    std::vector<HopOperand> fwd;  // A_k       [n_rows x n_cols], caller-owned arrays
+    std::vector<HopOperand> adj;  // A_k^T     [n_cols x n_rows], plan-owned arrays
+    std::deque<DeviceBuf> owned;  // storage behind `adj` (deque: references stay valid on growth)
+    // long-segment lists are specific to a hop selection; built on first use, then cached
+    mutable std::mutex mu;
+    mutable std::map<uint64_t, LongList> long_cache;  // key = mask | (adjoint << 32)
+};
+
+namespace {
+
+using h2gcn::HopCsr;
+using h2gcn::LaunchParams;
+
+// Host transposition of one CSR (counting sort by column; keeps ascending row order inside each output row,
+// i.e. the canonical order `tf.sparse.reorder` would give the adjoint operand).
+int transpose_csr_host(int64_t n_rows, int64_t n_cols, const std::vector<int64_t>& rowptr,
+                       const std::vector<int32_t>& colidx, const std::vector<float>& vals,
+                       std::vector<int64_t>& t_rowptr, std::vector<int32_t>& t_colidx, std::vector<float>& t_vals) {
+    const int64_t nnz = rowptr[n_rows];
+    t_rowptr.assign(n_cols + 1, 0);
+    t_colidx.resize(nnz);
+    t_vals.resize(nnz);
+    for (int64_t i = 0; i < nnz; ++i) t_rowptr[colidx[i] + 1]++;
+    for (int64_t c = 0; c < n_cols; ++c) t_rowptr[c + 1] += t_rowptr[c];
+    std::vector<int64_t> cursor(t_rowptr.begin(), t_rowptr.end() - 1);
+    for (int64_t r = 0; r < n_rows; ++r) {
+        for (int64_t i = rowptr[r]; i < rowptr[r + 1]; ++i) {
+            const int64_t dst = cursor[colidx[i]]++;
+            t_colidx[dst] = (int32_t)r;
+            t_vals[dst] = vals[i];
+        }
+    }
+    return 0;
+}
+
+void collect_long_rows(const std::vector<int64_t>& rowptr, int64_t n_rows, int threshold, std::vector<int64_t>& out) {
+    out.clear();
+    for (int64_t r = 0; r < n_rows; ++r)
+        if (rowptr[r + 1] - rowptr[r] >= threshold) out.push_back(r);
+}
+
+int check_rowptr(const std::vector<int64_t>& rowptr, int64_t n_rows, int hop) {
+    if (rowptr[0] != 0) return fail(H2GCN_ERR_BAD_INDEX, "hop %d: rowptr[0] = %lld, expected 0", hop, (long long)rowptr[0]);
+    for (int64_t r = 0; r < n_rows; ++r)
+        if (rowptr[r + 1] < rowptr[r])
+            return fail(H2GCN_ERR_BAD_INDEX, "hop %d: rowptr decreases at row %lld", hop, (long long)r);
+    return H2GCN_OK;
+}
+
+// Long-segment list for a hop selection (cached in the plan).
+int get_long_list(const h2gcn_plan* plan, bool adjoint, uint32_t mask, const int64_t** dev_out, int* n_out) {
+    const uint64_t key = (uint64_t)mask | ((uint64_t)(adjoint ? 1 : 0) << 32);
+    std::lock_guard<std::mutex> lock(plan->mu);
+    auto it = plan->long_cache.find(key);
+    if (it == plan->long_cache.end()) {
+        const std::vector<HopOperand>& ops = adjoint ? plan->adj : plan->fwd;
+        std::vector<int64_t> host;
+        int s = 0;
+        if (!adjoint) {
+            // forward: one entry per long (row, selected hop) segment, encoded row << 4 | s
+            for (int k = 0; k < plan->n_hops; ++k) {
+                if (!(mask & (1u << k))) continue;
+                for (int64_t r : ops[k].long_rows) host.push_back((r << 4) | s);
+                ++s;
+            }
+        } else {
+            // adjoint (sum over hops): a row is long if any selected hop segment is
+            for (int k = 0; k < plan->n_hops; ++k) {
+                if (!(mask & (1u << k))) continue;
+                host.insert(host.end(), ops[k].long_rows.begin(), ops[k].long_rows.end());
+            }
+            std::sort(host.begin(), host.end());
+            host.erase(std::unique(host.begin(), host.end()), host.end());
+        }
+        LongList& ll = plan->long_cache[key];
+        ll.n = (int)host.size();
+        if (ll.n > 0) {
+            H2GCN_HIP_TRY(hipMalloc(&ll.dev.p, host.size() * sizeof(int64_t)));
+            H2GCN_HIP_TRY(hipMemcpy(ll.dev.p, host.data(), host.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        }
+        it = plan->long_cache.find(key);
+    }
+    *dev_out = (const int64_t*)it->second.dev.p;
+    *n_out = it->second.n;
+    return H2GCN_OK;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <bool SUM>
+int launch(const LaunchParams& p, int variant, bool vec_ok, hipStream_t stream) {
+    using namespace h2gcn;
+    const int64_t n_blocks = (int64_t)p.n_long + p.tiles_per_xcd * kNumXcd;
+    if (n_blocks <= 0) return H2GCN_OK;
+    if (n_blocks > 0x7fffffffLL) return fail(H2GCN_ERR_INVALID_ARGUMENT, "grid too large (%lld blocks)", (long long)n_blocks);
+    const dim3 grid((unsigned)n_blocks), block(kBlock);
+#define H2GCN_LAUNCH(VEC, LPR, EXACT) \
+    hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM>), grid, block, 0, stream, p)
+    if (vec_ok && variant == 1 && p.d == 128) {
+        H2GCN_LAUNCH(2, 64, true);  // one neighbour per load instruction, scalar base addressing
+    } else if (vec_ok && p.d == 256) {
+        H2GCN_LAUNCH(4, 64, true);
+    } else if (vec_ok && p.d == 128) {
+        H2GCN_LAUNCH(4, 32, true);
+    } else if (vec_ok && p.d == 64) {
+        H2GCN_LAUNCH(4, 16, true);
+    } else if (vec_ok && p.d == 32) {
+        H2GCN_LAUNCH(4, 8, true);
+    } else if (vec_ok && p.d % 4 == 0) {
+        H2GCN_LAUNCH(4, 64, false);
+    } else {
+        H2GCN_LAUNCH(1, 64, false);
+    }
+#undef H2GCN_LAUNCH
+    H2GCN_HIP_TRY(hipGetLastError());
+    return H2GCN_OK;
+}
+
+int resolve_mask(const h2gcn_plan* plan, uint32_t hop_mask, uint32_t* out) {
+    const uint32_t all = plan->n_hops >= 32 ? 0xffffffffu : ((1u << plan->n_hops) - 1u);
+    if (hop_mask == 0) hop_mask = all;
+    if (hop_mask & ~all) return fail(H2GCN_ERR_INVALID_ARGUMENT, "hop_mask 0x%x selects hops beyond the plan's %d", hop_mask, plan->n_hops);
+    *out = hop_mask;
+    return H2GCN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int h2gcn_abi_version(void) { return H2GCN_ABI_VERSION; }
+
+const char* h2gcn_last_error(void) { return g_last_error.c_str(); }
+
+int h2gcn_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(H2GCN_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return n;
+}
+
+int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t* const* rowptr_dev,
+                      const int32_t* const* colidx_dev, const float* const* vals_dev,
+                      const h2gcn_plan_opts* opts, void* stream_v, h2gcn_plan_t** out_plan) {
+    try {
+        if (!out_plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "out_plan is NULL");
+        *out_plan = nullptr;
+        if (n_hops < 1 || n_hops > H2GCN_MAX_HOPS)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "n_hops = %d, supported 1..%d", n_hops, H2GCN_MAX_HOPS);
+        if (n_rows < 0 || n_cols < 0 || n_cols > 0x7fffffffLL)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad shape %lld x %lld (column ids are int32)", (long long)n_rows, (long long)n_cols);
+        if (n_rows >= (1LL << 58)) return fail(H2GCN_ERR_INVALID_ARGUMENT, "n_rows too large");
+        if (!rowptr_dev || !colidx_dev || !vals_dev) return fail(H2GCN_ERR_INVALID_ARGUMENT, "NULL operand table");
+        h2gcn_plan_opts o;
+        memset(&o, 0, sizeof(o));
+        if (opts) {
+            if (opts->struct_size < 8 || opts->struct_size > sizeof(o))
+                return fail(H2GCN_ERR_INVALID_ARGUMENT, "opts->struct_size = %u", opts->struct_size);
+            memcpy(&o, opts, opts->struct_size);
+        }
+        if (o.long_row_threshold < 0 || o.rows_per_wave < 0 || o.rows_per_wave > h2gcn::kMaxRowsPerWave)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad tunable (long_row_threshold %d, rows_per_wave %d, max %d)",
+                        o.long_row_threshold, o.rows_per_wave, h2gcn::kMaxRowsPerWave);
+        hipStream_t stream = (hipStream_t)stream_v;
+
+        std::unique_ptr<h2gcn_plan> plan(new h2gcn_plan());
+        plan->n_hops = n_hops;
+        plan->n_rows = n_rows;
+        plan->n_cols = n_cols;
+        if (o.long_row_threshold > 0) plan->long_threshold = o.long_row_threshold;
+        if (o.rows_per_wave > 0) plan->rows_per_wave = o.rows_per_wave;
+        // (rows_per_wave + 1) * n_hops row pointers must fit one 64-lane load
+        while ((plan->rows_per_wave + 1) * n_hops > h2gcn::kWave && plan->rows_per_wave > 1) plan->rows_per_wave--;
+        plan->variant = o.variant;
+        H2GCN_HIP_TRY(hipGetDevice(&plan->device));
+        plan->fwd.resize(n_hops);
+
+        DeviceBuf flag;
+        H2GCN_HIP_TRY(hipMalloc(&flag.p, sizeof(int)));
+        H2GCN_HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int), stream));
+
+        std::vector<std::vector<int64_t>> h_rowptr(n_hops);
+        for (int k = 0; k < n_hops; ++k) {
+            if (!rowptr_dev[k]) return fail(H2GCN_ERR_INVALID_ARGUMENT, "hop %d: rowptr is NULL", k);
+            h_rowptr[k].resize(n_rows + 1);
+            H2GCN_HIP_TRY(hipMemcpyAsync(h_rowptr[k].data(), rowptr_dev[k], (n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+        }
+        H2GCN_HIP_TRY(hipStreamSynchronize(stream));
+        for (int k = 0; k < n_hops; ++k) {
+            int st = check_rowptr(h_rowptr[k], n_rows, k);
+            if (st != H2GCN_OK) return st;
+            HopOperand& op = plan->fwd[k];
+            op.rowptr = rowptr_dev[k];
+            op.colidx = colidx_dev[k];
+            op.vals = vals_dev[k];
+            op.nnz = h_rowptr[k][n_rows];
+            if (op.nnz > 0 && (!op.colidx || !op.vals)) return fail(H2GCN_ERR_INVALID_ARGUMENT, "hop %d: colidx/vals is NULL", k);
+            collect_long_rows(h_rowptr[k], n_rows, plan->long_threshold, op.long_rows);
+            if (!(o.flags & H2GCN_PLAN_SKIP_VALIDATION) && op.nnz > 0) {
+                const int64_t want = (op.nnz + 255) / 256;
+                const unsigned blocks = (unsigned)std::min<int64_t>(want, 4096);
+                hipLaunchKernelGGL(h2gcn::check_colidx_kernel, dim3(blocks), dim3(256), 0, stream, op.colidx, op.nnz, n_cols, (int*)flag.p);
+                H2GCN_HIP_TRY(hipGetLastError());
+            }
+        }
+        int h_flag = 0;
+        H2GCN_HIP_TRY(hipMemcpyAsync(&h_flag, flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+        H2GCN_HIP_TRY(hipStreamSynchronize(stream));
+        if (h_flag) return fail(H2GCN_ERR_BAD_INDEX, "a column index lies outside [0, %lld)", (long long)n_cols);
+
+        if (o.flags & H2GCN_PLAN_BUILD_TRANSPOSE) {
+            if (n_rows > 0x7fffffffLL) return fail(H2GCN_ERR_INVALID_ARGUMENT, "transpose needs n_rows < 2^31");
+            plan->adj.resize(n_hops);
+            for (int k = 0; k < n_hops; ++k) {
+                const int64_t nnz = plan->fwd[k].nnz;
+                std::vector<int32_t> h_col(nnz);
+                std::vector<float> h_val(nnz);
+                if (nnz > 0) {
+                    H2GCN_HIP_TRY(hipMemcpy(h_col.data(), colidx_dev[k], nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+                    H2GCN_HIP_TRY(hipMemcpy(h_val.data(), vals_dev[k], nnz * sizeof(float), hipMemcpyDeviceToHost));
+                }
+                std::vector<int64_t> t_rowptr;
+                std::vector<int32_t> t_col;
+                std::vector<float> t_val;
+                transpose_csr_host(n_rows, n_cols, h_rowptr[k], h_col, h_val, t_rowptr, t_col, t_val);
+                plan->owned.emplace_back();
+                DeviceBuf& d_rp = plan->owned.back();
+                H2GCN_HIP_TRY(hipMalloc(&d_rp.p, (n_cols + 1) * sizeof(int64_t)));
+                H2GCN_HIP_TRY(hipMemcpy(d_rp.p, t_rowptr.data(), (n_cols + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+                plan->owned.emplace_back();
+                DeviceBuf& d_ci = plan->owned.back();
+                plan->owned.emplace_back();
+                DeviceBuf& d_va = plan->owned.back();
+                if (nnz > 0) {
+                    H2GCN_HIP_TRY(hipMalloc(&d_ci.p, nnz * sizeof(int32_t)));
+                    H2GCN_HIP_TRY(hipMemcpy(d_ci.p, t_col.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+                    H2GCN_HIP_TRY(hipMalloc(&d_va.p, nnz * sizeof(float)));
+                    H2GCN_HIP_TRY(hipMemcpy(d_va.p, t_val.data(), nnz * sizeof(float), hipMemcpyHostToDevice));
+                }
+                HopOperand& op = plan->adj[k];
+                op.rowptr = (const int64_t*)d_rp.p;
+                op.colidx = (const int32_t*)d_ci.p;
+                op.vals = (const float*)d_va.p;
+                op.nnz = nnz;
+                collect_long_rows(t_rowptr, n_cols, plan->long_threshold, op.long_rows);
+            }
+            plan->has_transpose = true;
+        }
+        *out_plan = plan.release();
+        return H2GCN_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(H2GCN_ERR_OUT_OF_MEMORY, "host allocation failed in plan_create");
+    } catch (...) {
+        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in plan_create");
+    }
+}
+
+void h2gcn_plan_destroy(h2gcn_plan_t* plan) { delete plan; }
+
+int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t* n_cols, int64_t* nnz,
+                    int64_t* n_long_segments, int32_t* has_transpose) {
+    if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (hop < 0 || hop >= plan->n_hops) return fail(H2GCN_ERR_INVALID_ARGUMENT, "hop %d outside 0..%d", hop, plan->n_hops - 1);
+    if (n_rows) *n_rows = plan->n_rows;
+    if (n_cols) *n_cols = plan->n_cols;
+    if (nnz) *nnz = plan->fwd[hop].nnz;
+    if (n_long_segments) *n_long_segments = (int64_t)plan->fwd[hop].long_rows.size();
+    if (has_transpose) *has_transpose = plan->has_transpose ? 1 : 0;
+    return H2GCN_OK;
+}
+
+int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X, int64_t ldx, int32_t d,
+                        float* Y, int64_t ldy_row, int64_t ldy_hop, void* stream_v) {
+    try {
+        if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
+        uint32_t mask;
+        int st = resolve_mask(plan, hop_mask, &mask);
+        if (st != H2GCN_OK) return st;
+        if (d < 1) return fail(H2GCN_ERR_INVALID_ARGUMENT, "d = %d", d);
+        if (plan->n_rows == 0) return H2GCN_OK;
+        if (!Y) return fail(H2GCN_ERR_INVALID_ARGUMENT, "Y is NULL");
+        if (!X && plan->n_cols > 0) return fail(H2GCN_ERR_INVALID_ARGUMENT, "X is NULL");
+        if (ldx < d) return fail(H2GCN_ERR_INVALID_ARGUMENT, "ldx = %lld < d = %d", (long long)ldx, d);
+        if (ldy_hop < 0 || ldy_row < 0) return fail(H2GCN_ERR_INVALID_ARGUMENT, "negative output stride");
+        LaunchParams p;
+        memset(&p, 0, sizeof(p));
+        int s = 0;
+        bool vec_ok = aligned16(X) && aligned16(Y) && ldx % 4 == 0 && ldy_row % 4 == 0;
+        for (int k = 0; k < plan->n_hops; ++k) {
+            if (!(mask & (1u << k))) continue;
+            const HopOperand& op = plan->fwd[k];
+            p.hop[s] = HopCsr{op.rowptr, op.colidx, op.vals};
+            p.src_hop_off[s] = 0;
+            p.dst_hop_off[s] = (int64_t)s * ldy_hop;
+            vec_ok = vec_ok && (p.dst_hop_off[s] % 4 == 0);
+            ++s;
+        }
+        p.n_sel = s;
+        if (s > 1 && ldy_hop < d) return fail(H2GCN_ERR_INVALID_ARGUMENT, "ldy_hop = %lld < d = %d: hop outputs would overlap", (long long)ldy_hop, d);
+        p.d = d;
+        p.n_rows = plan->n_rows;
+        p.src = X;
+        p.ld_src = ldx;
+        p.dst = Y;
+        p.ld_dst = ldy_row;
+        st = get_long_list(plan, false, mask, &p.long_list, &p.n_long);
+        if (st != H2GCN_OK) return st;
+        p.long_threshold = plan->long_threshold;
+        p.rows_per_wave = plan->rows_per_wave;
+        const int64_t rows_per_tile = (int64_t)p.rows_per_wave * h2gcn::kWavesPerBlock;
+        p.n_tiles = (p.n_rows + rows_per_tile - 1) / rows_per_tile;
+        p.tiles_per_xcd = (p.n_tiles + h2gcn::kNumXcd - 1) / h2gcn::kNumXcd;
+        return launch<false>(p, plan->variant, vec_ok, (hipStream_t)stream_v);
+    } catch (...) {
+        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_f32");
+    }
+}
+
+int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* dY, int64_t ldg_row,
+                          int64_t ldg_hop, int32_t d, float* dX, int64_t ldx, void* stream_v) {
+    try {
+        if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
+        if (!plan->has_transpose)
+            return fail(H2GCN_ERR_NO_TRANSPOSE, "plan was created without H2GCN_PLAN_BUILD_TRANSPOSE");
+        uint32_t mask;
+        int st = resolve_mask(plan, hop_mask, &mask);
+        if (st != H2GCN_OK) return st;
+        if (d < 1) return fail(H2GCN_ERR_INVALID_ARGUMENT, "d = %d", d);
+        if (plan->n_cols == 0) return H2GCN_OK;
+        if (!dX) return fail(H2GCN_ERR_INVALID_ARGUMENT, "dX is NULL");
+        if (!dY && plan->n_rows > 0) return fail(H2GCN_ERR_INVALID_ARGUMENT, "dY is NULL");
+        if (ldx < d) return fail(H2GCN_ERR_INVALID_ARGUMENT, "ldx = %lld < d = %d", (long long)ldx, d);
+        if (ldg_row < d || ldg_hop < 0) return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad gradient strides");
+        LaunchParams p;
+        memset(&p, 0, sizeof(p));
+        int s = 0;
+        bool vec_ok = aligned16(dY) && aligned16(dX) && ldx % 4 == 0 && ldg_row % 4 == 0;
+        for (int k = 0; k < plan->n_hops; ++k) {
+            if (!(mask & (1u << k))) continue;
+            const HopOperand& op = plan->adj[k];
+            p.hop[s] = HopCsr{op.rowptr, op.colidx, op.vals};
+            p.src_hop_off[s] = (int64_t)s * ldg_hop;
+            p.dst_hop_off[s] = 0;
+            vec_ok = vec_ok && (p.src_hop_off[s] % 4 == 0);
+            ++s;
+        }
+        p.n_sel = s;
+        p.d = d;
+        p.n_rows = plan->n_cols;
+        p.src = dY;
+        p.ld_src = ldg_row;
+        p.dst = dX;
+        p.ld_dst = ldx;
+        st = get_long_list(plan, true, mask, &p.long_list, &p.n_long);
+        if (st != H2GCN_OK) return st;
+        p.long_threshold = plan->long_threshold;
+        p.rows_per_wave = plan->rows_per_wave;
+        const int64_t rows_per_tile = (int64_t)p.rows_per_wave * h2gcn::kWavesPerBlock;
+        p.n_tiles = (p.n_rows + rows_per_tile - 1) / rows_per_tile;
+        p.tiles_per_xcd = (p.n_tiles + h2gcn::kNumXcd - 1) / h2gcn::kNumXcd;
+        return launch<true>(p, plan->variant, vec_ok, (hipStream_t)stream_v);
+    } catch (...) {
+        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_T_f32");
+    }
+}
+
+}  // extern "C"

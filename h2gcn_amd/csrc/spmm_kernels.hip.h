@@ -1,0 +1,360 @@
+// spmm_kernels.hip.h -- gfx950 device code of the fused multi-hop CSR x dense aggregation.
+//
+// What it computes (reference h2gcn/models/_layers.py:78-81, GCNLayer.call):
+//     Y[i, s, :] = sum_j A_s[i, j] * X[j, :]          for every selected hop s, fused in ONE launch,
+// and, in SUM mode (the adjoint, reference gradient of SparseTensorDenseMatMul wrt its dense operand,
+// reached from h2gcn/models/H2GCN.py:66-74):
+//     dX[i, :]   = sum_s sum_j At_s[i, j] * dY[j, s, :].
+//
+// Hardware mapping (MI355X / CDNA4, wave64; the path is HBM-gather bound -- no MFMA on purpose):
+//   * one wavefront walks a few consecutive rows ("CSR-adaptive, wave per row"); the feature row it gathers
+//     per nonzero is contiguous (d*4 bytes), read with one 16-byte load per lane: LPR = d/4 lanes cover a
+//     row, so a wave gathers G = 64/LPR neighbour rows per load instruction (d=128: 2 x 512 B = 1 KiB);
+//   * column ids / values of a row are fetched 64 at a time with one coalesced load per wave and handed to
+//     the lane groups with ds_bpermute (G>1) or v_readlane + scalar base addressing (G==1);
+//   * loads are issued in batches of UNROLL before the first FMA so that >= 8 KiB per wave is in flight;
+//   * partial sums of the G lane groups are folded with gfx950 v_permlane32_swap / v_permlane16_swap
+//     (no LDS round trip), then LPR lanes write the output row with 16-byte non-temporal stores;
+//   * (row,hop) segments with >= long_row_threshold nonzeros are taken out of the regular path and split
+//     over the 4 waves of a workgroup: LDS-staged partial sums, summed in fixed wave order (deterministic);
+//   * the block -> row-tile map gives every XCD (private L2) a contiguous range of rows.
+//
+// Floating point: fp32 multiply-add per nonzero.  Inside a lane group the accumulation order is ascending
+// column order, as in the reference's CPU kernel; the G group partials (and the 4 wave partials of a long
+// segment) are then added pairwise, which is the only reordering vs. a sequential sum.  The order depends
+// only on the row's own nonzeros, never on the launch geometry, so row-partitioned multi-GPU runs reproduce
+// the single-GPU result bit-for-bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "h2gcn_hip.h"
+
+namespace h2gcn {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+constexpr int kNumXcd = 8;
+constexpr int kMaxRowsPerWave = 7;  // (rows_per_wave + 1) * n_hops row pointers must fit one wave-wide load
+constexpr int kMaxTileCols = 256;   // columns one pass of a wave covers at most (64 lanes x float4)
+
+struct HopCsr {
+    const int64_t* rowptr;
+    const int32_t* colidx;
+    const float* vals;
+};
+
+struct LaunchParams {
+    HopCsr hop[H2GCN_MAX_HOPS];          // the selected hops, packed
+    int64_t src_hop_off[H2GCN_MAX_HOPS]; // element offset added to the gather source for hop s
+    int64_t dst_hop_off[H2GCN_MAX_HOPS]; // element offset added to the output for hop s (ignored in SUM mode)
+    int n_sel;
+    int d;
+    int64_t n_rows;  // rows of the output
+    const float* src;
+    int64_t ld_src;
+    float* dst;
+    int64_t ld_dst;
+    const int64_t* long_list; // forward: (row << 4 | s) per long segment; SUM: row per long row
+    int n_long;
+    int long_threshold;
+    int rows_per_wave;
+    int64_t n_tiles;       // row tiles of rows_per_wave * kWavesPerBlock rows
+    int64_t tiles_per_xcd; // ceil(n_tiles / 8)
+};
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<1> {
+    using type = float;
+};
+template <>
+struct VecT<2> {
+    using type = float __attribute__((ext_vector_type(2)));
+};
+template <>
+struct VecT<4> {
+    using type = float __attribute__((ext_vector_type(4)));
+};
+
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// value of `v` held by lane `src_lane` (src_lane may differ per lane): ds_bpermute_b32
+__device__ __forceinline__ int lane_gather(int v, int src_lane) {
+    return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
+}
+__device__ __forceinline__ float lane_gather(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+
+// sum over the lanes {l, l^32}: v_permlane32_swap (gfx950)
+__device__ __forceinline__ float fold_xor32(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over the lanes {l, l^16}: v_permlane16_swap (gfx950)
+__device__ __forceinline__ float fold_xor16(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over {l, l^8}: DPP row_ror:8 inside each row of 16 lanes
+__device__ __forceinline__ float fold_xor8(float v) {
+    const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+    return v + __int_as_float(o);
+}
+
+// Fold the partial sums of the G = 64/LPR lane groups; afterwards every group holds the total.
+// Fixed tree: (g, g^1) first ... independent of anything but LPR.
+template <int LPR>
+__device__ __forceinline__ float fold_groups(float v) {
+    if constexpr (LPR <= 8) v = fold_xor8(v);
+    if constexpr (LPR <= 16) v = fold_xor16(v);
+    if constexpr (LPR <= 32) v = fold_xor32(v);
+    return v;
+}
+
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type load_vec(const float* p) {
+    return *reinterpret_cast<const typename VecT<VEC>::type*>(p);
+}
+
+template <int VEC>
+__device__ __forceinline__ void fma_vec(float (&acc)[VEC], float w, typename VecT<VEC>::type x) {
+    if constexpr (VEC == 1) {
+        acc[0] = fmaf(w, x, acc[0]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(w, x[i], acc[i]);
+    }
+}
+
+// One batch of U gathers issued back to back, then U multiply-adds.  `t` is the first step of the batch
+// (wave uniform); step t+u serves neighbour (t+u)*G + g of the current 64-wide chunk.
+template <int VEC, int LPR, int U, bool MASKED>
+__device__ __forceinline__ void gather_batch(int c, float v, int t, int g, const float* __restrict__ src_lane,
+                                             int64_t ld, bool lane_active, float (&acc)[VEC]) {
+    constexpr int G = kWave / LPR;
+    typename VecT<VEC>::type x[U];
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        int cj;
+        if constexpr (G == 1) {
+            // wave-uniform neighbour: v_readlane -> SGPR, the load uses a scalar base + lane offset
+            cj = __builtin_amdgcn_readlane(c, t + u);
+            w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t + u));
+        } else {
+            const int idx = (t + u) * G + g;
+            cj = lane_gather(c, idx);
+            w[u] = lane_gather(v, idx);
+        }
+        const float* p = src_lane + (int64_t)cj * ld;
+        if constexpr (MASKED) {
+            if (lane_active) {
+                x[u] = load_vec<VEC>(p);
+            } else {
+                if constexpr (VEC == 1) x[u] = 0.f; else x[u] = (typename VecT<VEC>::type)(0.f);
+            }
+        } else {
+            x[u] = load_vec<VEC>(p);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) fma_vec<VEC>(acc, w[u], x[u]);
+}
+
+// Accumulate sum_j val_j * src[col_j, :] over the nonzeros [seg_begin, seg_end) of one CSR row, taking the
+// 64-wide chunks chunk0, chunk0+chunk_step, ... (regular path: all of them; long path: this wave's share).
+// Each lane group accumulates its neighbours in ascending order into acc.
+template <int VEC, int LPR, bool MASKED>
+__device__ __forceinline__ void accumulate_segment(const int32_t* __restrict__ colidx,
+                                                   const float* __restrict__ vals, int64_t seg_begin,
+                                                   int64_t seg_end, int chunk0, int chunk_step,
+                                                   const float* __restrict__ src_lane, int64_t ld, int lane,
+                                                   bool lane_active, float (&acc)[VEC]) {
+    constexpr int G = kWave / LPR;
+    const int g = lane / LPR;
+    for (int64_t base = seg_begin + (int64_t)chunk0 * kWave; base < seg_end; base += (int64_t)chunk_step * kWave) {
+        const int64_t left = seg_end - base;
+        const int n = left < kWave ? (int)left : kWave;
+        int c = 0;
+        float v = 0.f;
+        if (lane < n) {
+            c = __builtin_nontemporal_load(colidx + base + lane);
+            v = __builtin_nontemporal_load(vals + base + lane);
+        }
+        const int full = n / G;  // steps in which every lane group has a neighbour
+        int t = 0;
+        for (; t + 8 <= full; t += 8) gather_batch<VEC, LPR, 8, MASKED>(c, v, t, g, src_lane, ld, lane_active, acc);
+        if (t + 4 <= full) {
+            gather_batch<VEC, LPR, 4, MASKED>(c, v, t, g, src_lane, ld, lane_active, acc);
+            t += 4;
+        }
+        if (t + 2 <= full) {
+            gather_batch<VEC, LPR, 2, MASKED>(c, v, t, g, src_lane, ld, lane_active, acc);
+            t += 2;
+        }
+        if (t + 1 <= full) {
+            gather_batch<VEC, LPR, 1, MASKED>(c, v, t, g, src_lane, ld, lane_active, acc);
+            t += 1;
+        }
+        if constexpr (G > 1) {
+            // ragged last step: only the first (n - full*G) groups still have a neighbour.  Predicated, so
+            // that padding never touches src (0 * Inf would poison the row).
+            const int rem = n - full * G;
+            if (g < rem) gather_batch<VEC, LPR, 1, MASKED>(c, v, full, g, src_lane, ld, lane_active, acc);
+        }
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&acc)[VEC]) {
+    if constexpr (VEC == 1) {
+        __builtin_nontemporal_store(acc[0], p);
+    } else {
+        typename VecT<VEC>::type o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = acc[i];
+        __builtin_nontemporal_store(o, reinterpret_cast<typename VecT<VEC>::type*>(p));
+    }
+}
+
+// VEC   floats per lane per gathered row (4 on the fast paths)
+// LPR   lanes that cover one gathered row (EXACT: d == VEC*LPR; otherwise 64 and the columns are tiled)
+// EXACT d == VEC*LPR: one pass, no column masks
+// SUM   adjoint mode: one output row = sum over the selected hops
+template <int VEC, int LPR, bool EXACT, bool SUM>
+__global__ __launch_bounds__(kBlock) void spmm_hops_kernel(const LaunchParams p) {
+    constexpr int G = kWave / LPR;
+    static_assert(EXACT || LPR == kWave, "column-tiled path uses the whole wave per row");
+    __shared__ float partial[kWavesPerBlock][kMaxTileCols];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = wave_uniform(threadIdx.x >> 6);
+    const int li = lane % LPR;  // lane inside its group
+    const int g = lane / LPR;
+    const int n_sel = p.n_sel;
+    const int tile_cols = EXACT ? VEC * LPR : ((p.d < VEC * kWave) ? p.d : VEC * kWave);
+    (void)tile_cols;
+
+    if ((int)blockIdx.x < p.n_long) {
+        // ---- long segment: the 4 waves of this workgroup share one (row, hop) [forward] / one row [SUM] ----
+        const int64_t entry = p.long_list[blockIdx.x];
+        const int64_t row = SUM ? entry : (entry >> 4);
+        const int s_first = SUM ? 0 : (int)(entry & 15);
+        const int s_last = SUM ? n_sel : s_first + 1;
+        for (int col0 = 0; col0 < p.d; col0 += VEC * LPR) {
+            const bool lane_active = EXACT || (col0 + li * VEC < p.d);
+            float acc[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            for (int s = s_first; s < s_last; ++s) {
+                const HopCsr& h = p.hop[s];
+                const int64_t b = h.rowptr[row], e = h.rowptr[row + 1];
+                accumulate_segment<VEC, LPR, !EXACT>(h.colidx, h.vals, b, e, wave, kWavesPerBlock,
+                                                     p.src + p.src_hop_off[s] + col0 + li * VEC, p.ld_src, lane,
+                                                     lane_active, acc);
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
+            if (g == 0) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) partial[wave][li * VEC + i] = acc[i];
+            }
+            __syncthreads();
+            // fixed-order sum of the 4 wave partials; thread c owns column col0 + c
+            const int c = threadIdx.x;
+            if (c < VEC * LPR && col0 + c < p.d) {
+                float t = partial[0][c];
+#pragma unroll
+                for (int w = 1; w < kWavesPerBlock; ++w) t += partial[w][c];
+                const int64_t off = row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_first]) + col0 + c;
+                __builtin_nontemporal_store(t, p.dst + off);
+            }
+            if (!EXACT) __syncthreads();
+        }
+        return;
+    }
+
+    // ---- regular path: XCD-aware tile map, each wave walks rows_per_wave consecutive rows ----
+    const int64_t tb = (int64_t)blockIdx.x - p.n_long;
+    const int64_t tile = (tb % kNumXcd) * p.tiles_per_xcd + tb / kNumXcd;
+    if (tile >= p.n_tiles) return;
+    const int rpw = p.rows_per_wave;
+    const int64_t row0 = (tile * kWavesPerBlock + wave) * rpw;
+    if (row0 >= p.n_rows) return;
+    const int64_t rows_here_l = p.n_rows - row0;
+    const int rows_here = rows_here_l < rpw ? (int)rows_here_l : rpw;
+
+    // one wave-wide load fetches every row pointer this wave needs: lane l -> hop l/(rpw+1), row l%(rpw+1)
+    int64_t rp = 0;
+    {
+        const int hs = lane / (rpw + 1), r = lane % (rpw + 1);
+        if (hs < n_sel && r <= rows_here) rp = p.hop[hs].rowptr[row0 + r];
+    }
+    const int rp_lo = (int)(rp & 0xffffffff), rp_hi = (int)(rp >> 32);
+
+    for (int r = 0; r < rows_here; ++r) {
+        const int64_t row = row0 + r;
+        bool skip_row = false;
+        if constexpr (SUM) {
+            for (int s = 0; s < n_sel; ++s) {
+                const int l0 = s * (rpw + 1) + r;
+                const int64_t b = ((int64_t)__builtin_amdgcn_readlane(rp_hi, l0) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane(rp_lo, l0);
+                const int64_t e = ((int64_t)__builtin_amdgcn_readlane(rp_hi, l0 + 1) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane(rp_lo, l0 + 1);
+                if (e - b >= p.long_threshold) skip_row = true;
+            }
+        }
+        if (skip_row) continue;
+        for (int col0 = 0; col0 < p.d; col0 += VEC * LPR) {
+            const bool lane_active = EXACT || (col0 + li * VEC < p.d);
+            float acc[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            for (int s = 0; s < n_sel; ++s) {
+                const int l0 = s * (rpw + 1) + r;
+                const int64_t b = ((int64_t)__builtin_amdgcn_readlane(rp_hi, l0) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane(rp_lo, l0);
+                const int64_t e = ((int64_t)__builtin_amdgcn_readlane(rp_hi, l0 + 1) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane(rp_lo, l0 + 1);
+                if (!SUM && e - b >= p.long_threshold) continue;  // a workgroup of the long path owns it
+                const HopCsr& h = p.hop[s];
+                accumulate_segment<VEC, LPR, !EXACT>(h.colidx, h.vals, b, e, 0, 1,
+                                                     p.src + p.src_hop_off[s] + col0 + li * VEC, p.ld_src, lane,
+                                                     lane_active, acc);
+                if constexpr (!SUM) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
+                    if (g == 0 && lane_active)
+                        store_vec<VEC>(p.dst + row * p.ld_dst + p.dst_hop_off[s] + col0 + li * VEC, acc);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+                }
+            }
+            if constexpr (SUM) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
+                if (g == 0 && lane_active) store_vec<VEC>(p.dst + row * p.ld_dst + col0 + li * VEC, acc);
+            }
+        }
+    }
+}
+
+// one-time operand check of plan_create: any column id outside [0, n_cols) raises the flag
+__global__ void check_colidx_kernel(const int32_t* __restrict__ colidx, int64_t nnz, int64_t n_cols, int* flag) {
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t c = colidx[i];
+        bad |= (c < 0) | ((int64_t)c >= n_cols);
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+}  // namespace h2gcn

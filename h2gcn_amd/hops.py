@@ -1,0 +1,195 @@
+"""HopPlan -- the device-resident ``adj_hops`` operand list of H2GCN and its launch plan.
+
+Mirror of what the reference keeps in ``args.objects["tensors"]["adj_hops"]``: a Python list of H normalised
+``tf.SparseTensor`` built once before training (reference ``h2gcn/models/H2GCN.py:46-54`` ->
+``h2gcn/datasets/_dataset.py:559-576``, conversion ``sparse2Tensor`` ``:528-535``).  Here the list is one object:
+CSR arrays on the GPU (int64 row pointers, int32 column ids in ascending order per row -- the canonical order
+``tf.sparse.reorder`` establishes -- fp32 values) plus the opaque plan of ``libh2gcn_hip.so`` (row bins of the
+CSR-adaptive schedule, optional transposed operands for the backward pass).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Optional, Sequence
+
+import torch
+
+from . import _capi
+
+
+def _require(cond: bool, msg: str) -> None:
+    if not cond:
+        raise ValueError(msg)
+
+
+class HopPlan:
+    """H hop matrices sharing one row space, resident on one GPU.
+
+    Parameters
+    ----------
+    rowptr, colidx, vals : sequences of H CUDA tensors (int64 ``[n_rows+1]``, int32 ``[nnz]``, float32 ``[nnz]``)
+    n_cols : number of columns (rows of the dense operand ``X``)
+    build_transpose : also build ``A_k^T`` on the device (needed for ``backward``)
+    long_row_threshold, rows_per_wave, variant : schedule tunables (0 = library default)
+    validate : run the one-time column-range check (TensorFlow validates indices per call; this once)
+    """
+
+    def __init__(self, rowptr: Sequence[torch.Tensor], colidx: Sequence[torch.Tensor],
+                 vals: Sequence[torch.Tensor], n_cols: int, *, build_transpose: bool = False,
+                 long_row_threshold: int = 0, rows_per_wave: int = 0, variant: int = 0,
+                 validate: bool = True):
+        H = len(rowptr)
+        _require(1 <= H <= _capi.MAX_HOPS, f"need 1..{_capi.MAX_HOPS} hop matrices, got {H}")
+        _require(len(colidx) == H and len(vals) == H, "rowptr/colidx/vals lists differ in length")
+        dev = rowptr[0].device
+        _require(dev.type == "cuda", f"HopPlan operands must live on a GPU, got {dev} (no CPU fallback)")
+        n_rows = rowptr[0].numel() - 1
+        _require(n_rows >= 0, "rowptr must have n_rows+1 entries")
+        for k in range(H):
+            rp, ci, va = rowptr[k], colidx[k], vals[k]
+            _require(rp.dtype == torch.int64 and ci.dtype == torch.int32 and va.dtype == torch.float32,
+                     f"hop {k}: dtypes must be int64/int32/float32, got {rp.dtype}/{ci.dtype}/{va.dtype}")
+            _require(rp.device == dev and ci.device == dev and va.device == dev, f"hop {k}: operands on different devices")
+            _require(rp.dim() == 1 and rp.numel() == n_rows + 1, f"hop {k}: rowptr has {rp.numel()} entries, expected {n_rows + 1}")
+            _require(ci.dim() == 1 and va.dim() == 1 and ci.numel() == va.numel(), f"hop {k}: colidx/vals sizes differ")
+            _require(rp.is_contiguous() and ci.is_contiguous() and va.is_contiguous(), f"hop {k}: operands must be contiguous")
+        self.n_hops = H
+        self.n_rows = int(n_rows)
+        self.n_cols = int(n_cols)
+        self.device = dev
+        self.has_transpose = bool(build_transpose)
+        # the plan borrows these arrays: keep them alive
+        self.rowptr = list(rowptr)
+        self.colidx = list(colidx)
+        self.vals = list(vals)
+        self._handle = C.c_void_p()
+
+        L = _capi.lib()
+        arr_t = C.c_void_p * H
+        rp_a = arr_t(*[t.data_ptr() for t in self.rowptr])
+        ci_a = arr_t(*[t.data_ptr() for t in self.colidx])
+        va_a = arr_t(*[t.data_ptr() for t in self.vals])
+        opts = _capi.PlanOpts()
+        opts.struct_size = C.sizeof(_capi.PlanOpts)
+        opts.flags = (_capi.PLAN_BUILD_TRANSPOSE if build_transpose else 0) | (0 if validate else _capi.PLAN_SKIP_VALIDATION)
+        opts.long_row_threshold = int(long_row_threshold)
+        opts.rows_per_wave = int(rows_per_wave)
+        opts.variant = int(variant)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            st = L.h2gcn_plan_create(H, self.n_rows, self.n_cols, rp_a, ci_a, va_a, C.byref(opts),
+                                     C.c_void_p(stream), C.byref(self._handle))
+        _capi.check(st)
+
+    # ------------------------------------------------------------------ construction helpers
+    @classmethod
+    def from_scipy(cls, mats: Iterable, device, **kw) -> "HopPlan":
+        """Upload a list of scipy sparse matrices (any format; cast to fp32 CSR with sorted indices -- the
+        same cast/ordering ``sparse2Tensor`` applies, reference ``h2gcn/datasets/_dataset.py:528-535``)."""
+        import numpy as np
+        import scipy.sparse as sp
+
+        rowptr, colidx, vals = [], [], []
+        n_cols = None
+        n_rows = None
+        for m in mats:
+            m = sp.csr_matrix(m)
+            m.sum_duplicates()
+            m.sort_indices()
+            _require(n_cols in (None, m.shape[1]) and n_rows in (None, m.shape[0]), "hop matrices differ in shape")
+            n_rows, n_cols = m.shape
+            rowptr.append(torch.from_numpy(m.indptr.astype(np.int64)).to(device))
+            colidx.append(torch.from_numpy(m.indices.astype(np.int32)).to(device))
+            vals.append(torch.from_numpy(m.data.astype(np.float32)).to(device))
+        _require(n_cols is not None, "empty hop list")
+        return cls(rowptr, colidx, vals, n_cols, **kw)
+
+    # ------------------------------------------------------------------ introspection
+    @property
+    def nnz(self) -> list:
+        return [int(t.numel()) for t in self.colidx]
+
+    def info(self, hop: int) -> dict:
+        L = _capi.lib()
+        n_rows, n_cols, nnz, n_long = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        has_t = C.c_int32()
+        _capi.check(L.h2gcn_plan_info(self._handle, hop, C.byref(n_rows), C.byref(n_cols), C.byref(nnz),
+                                      C.byref(n_long), C.byref(has_t)))
+        return dict(n_rows=n_rows.value, n_cols=n_cols.value, nnz=nnz.value, n_long_segments=n_long.value,
+                    has_transpose=bool(has_t.value))
+
+    def _mask(self, hops) -> int:
+        if hops is None:
+            return 0
+        mask = 0
+        for h in hops:
+            _require(0 <= int(h) < self.n_hops, f"hop index {h} outside 0..{self.n_hops - 1}")
+            mask |= 1 << int(h)
+        _require(mask != 0, "empty hop selection")
+        return mask
+
+    def n_selected(self, hops) -> int:
+        return self.n_hops if hops is None else bin(self._mask(hops)).count("1")
+
+    # ------------------------------------------------------------------ launches
+    def spmm(self, x: torch.Tensor, hops=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``out[i, s, :] = sum_j A_s[i, j] * x[j, :]`` for the selected hops -> ``[n_rows, H_sel, d]``.
+
+        ``out`` may be any fp32 tensor view of shape ``[n_rows, H_sel, d]`` whose last dim is contiguous
+        (e.g. a column slice of a wider concat buffer)."""
+        _require(x.dim() == 2, f"inputs must be [n_cols, d], got shape {tuple(x.shape)}")
+        _require(x.dtype == torch.float32, f"inputs must be float32, got {x.dtype}")
+        _require(x.device == self.device, f"inputs on {x.device}, plan on {self.device}")
+        _require(x.shape[0] == self.n_cols, f"inputs have {x.shape[0]} rows, hop matrices have {self.n_cols} columns")
+        d = int(x.shape[1])
+        _require(d >= 1, "inputs need at least one column")
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        h_sel = self.n_selected(hops)
+        if out is None:
+            out = torch.empty((self.n_rows, h_sel, d), dtype=torch.float32, device=self.device)
+        else:
+            _require(out.dtype == torch.float32 and out.device == self.device, "out must be float32 on the plan's device")
+            _require(tuple(out.shape) == (self.n_rows, h_sel, d), f"out has shape {tuple(out.shape)}, expected {(self.n_rows, h_sel, d)}")
+            _require(d == 1 or out.stride(2) == 1, "out's last dimension must be contiguous")
+        if self.n_rows == 0:
+            return out
+        L = _capi.lib()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            st = L.h2gcn_spmm_hops_f32(self._handle, self._mask(hops), C.c_void_p(x.data_ptr()), x.stride(0), d,
+                                       C.c_void_p(out.data_ptr()), out.stride(0), out.stride(1) if h_sel > 1 else d,
+                                       C.c_void_p(stream))
+        _capi.check(st)
+        return out
+
+    def spmm_t(self, grad: torch.Tensor, hops=None) -> torch.Tensor:
+        """Adjoint: ``dx[j, :] = sum_s sum_i A_s[i, j] * grad[i, s, :]`` -> ``[n_cols, d]``."""
+        _require(self.has_transpose, "plan was built without build_transpose=True; backward is unavailable")
+        h_sel = self.n_selected(hops)
+        _require(grad.dim() == 3 and grad.shape[0] == self.n_rows and grad.shape[1] == h_sel,
+                 f"grad must be [{self.n_rows}, {h_sel}, d], got {tuple(grad.shape)}")
+        _require(grad.dtype == torch.float32 and grad.device == self.device, "grad must be float32 on the plan's device")
+        d = int(grad.shape[2])
+        if grad.stride(2) != 1 or grad.stride(0) < d or (h_sel > 1 and grad.stride(1) < d):
+            grad = grad.contiguous()  # e.g. an expanded (stride-0) gradient coming out of a reduction
+        dx = torch.empty((self.n_cols, d), dtype=torch.float32, device=self.device)
+        if self.n_cols == 0:
+            return dx
+        L = _capi.lib()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            st = L.h2gcn_spmm_hops_T_f32(self._handle, self._mask(hops), C.c_void_p(grad.data_ptr()),
+                                         grad.stride(0) if self.n_rows > 0 else d, grad.stride(1), d,
+                                         C.c_void_p(dx.data_ptr()), dx.stride(0), C.c_void_p(stream))
+        _capi.check(st)
+        return dx
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                _capi.lib().h2gcn_plan_destroy(h)
+            except Exception:
+                pass
+            self._handle = C.c_void_p()

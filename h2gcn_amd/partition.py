@@ -1,0 +1,77 @@
+"""Vertex/row partitioning of the hop aggregation over the GPUs of one node (new -- the reference is
+single-process, single-device: no collective appears anywhere in it).
+
+Scheme: rank p owns a contiguous block of rows of every hop matrix ``A_k[rows_p, :]`` (global
+column ids) and the matching rows of the embedding ``X[rows_p, :]``.  ``Y[i, k, :]`` depends only on row ``i`` of
+``A_k`` and on the rows of ``X`` its column ids name, so one exchange per layer suffices: all-gather ``X`` (RCCL
+``ncclAllGather`` over xGMI through ``torch.distributed``, backend "nccl"), then the local fused SpMM.  The
+per-row summation order does not depend on the partitioning, so P ranks reproduce the 1-rank result
+bit-for-bit.  Everything after the aggregation in H2GCN (concat, dropout, classifier) is row-local; the backward
+pass needs the mirror-image reduce-scatter of ``dX``.
+
+Rows are split into equal blocks (``ceil(N/P)`` rows, last block shorter or empty) so that the all-gather is a
+single fixed-count collective; the gathered buffer is padded to ``P * ceil(N/P)`` rows and viewed as ``[:N]``.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def block_bounds(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """[r0, r1) of ``rank``'s row block: equal blocks of ceil(n/P) rows."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError(f"bad rank {rank} / world size {world_size}")
+    per = -(-n_rows // world_size)
+    r0 = min(rank * per, n_rows)
+    return r0, min(r0 + per, n_rows)
+
+
+def rows_per_rank(n_rows: int, world_size: int) -> int:
+    return -(-n_rows // world_size)
+
+
+class EmbeddingAllGather:
+    """Reusable buffers + the per-layer all-gather of the row-sharded embedding.
+
+    ``gather(x_local)`` returns the full ``[n_rows, d]`` matrix (a view of an internal padded buffer that is
+    overwritten by the next call).  With ``world_size == 1`` it returns ``x_local`` itself -- no copy, no
+    collective."""
+
+    def __init__(self, n_rows: int, d: int, device, group: Optional[dist.ProcessGroup] = None,
+                 dtype=torch.float32):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.n_rows, self.d = int(n_rows), int(d)
+        self.per = rows_per_rank(self.n_rows, self.world)
+        self.r0, self.r1 = block_bounds(self.n_rows, self.world, self.rank)
+        if self.world > 1:
+            self.full = torch.empty((self.world * self.per, self.d), dtype=dtype, device=device)
+            self.send = torch.zeros((self.per, self.d), dtype=dtype, device=device)
+        else:
+            self.full = self.send = None
+
+    def gather(self, x_local: torch.Tensor) -> torch.Tensor:
+        if tuple(x_local.shape) != (self.r1 - self.r0, self.d):
+            raise ValueError(f"local embedding has shape {tuple(x_local.shape)}, expected {(self.r1 - self.r0, self.d)}")
+        if self.world == 1:
+            return x_local
+        if self.r1 - self.r0 == self.per and x_local.is_contiguous():
+            send = x_local
+        else:  # last (short) block: pad to the common count
+            self.send[: self.r1 - self.r0].copy_(x_local)
+            send = self.send
+        dist.all_gather_into_tensor(self.full, send, group=self.group)
+        return self.full[: self.n_rows]
+
+
+def shard_rows_scipy(mats, world_size: int, rank: int):
+    """Row block of each scipy hop matrix for ``rank`` (global column space kept)."""
+    out = []
+    for m in mats:
+        r0, r1 = block_bounds(m.shape[0], world_size, rank)
+        out.append(m[r0:r1])
+    return out

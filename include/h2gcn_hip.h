@@ -1,0 +1,149 @@
+/*
+ * h2gcn_hip.h -- C ABI of libh2gcn_hip.so: the MI355X (gfx950) hop-aggregation path of H2GCN.
+ *
+ * The library replaces exactly one thing in the reference (GemsLab/H2GCN): the sparse aggregation that
+ * `GCNLayer.call` performs through TensorFlow,
+ *
+ *     tf.stack([tf.sparse.sparse_dense_matmul(A_k, X) for A_k in adjhops], axis=-2)      -> [N, H, d]
+ *
+ * (reference h2gcn/models/_layers.py:54-81; the op underneath is TensorFlow's SparseTensorDenseMatMul,
+ * call sites _layers.py:74,76) and its gradient wrt X (`dX = sum_k A_k^T dY[:,k,:]`, reached from
+ * tape.gradient at h2gcn/models/H2GCN.py:66-74).  There is no native boundary in the reference to copy:
+ * the reference's native boundary is TensorFlow's op registry.  Each entry point below cites the reference
+ * behaviour it stands in for.
+ *
+ * Conventions
+ *   - plain C linkage, POD arguments, no C++/torch types, no exceptions across the boundary;
+ *   - every pointer named *_dev is a DEVICE pointer of the current HIP device, owned by the caller and
+ *     required to outlive the plan / the launch that uses it;
+ *   - every function returning int returns H2GCN_OK (0) or a negative h2gcn_status; the message for the last
+ *     failure on the calling thread is h2gcn_last_error();
+ *   - launches are asynchronous on the given stream (a hipStream_t passed as void*; NULL = default stream);
+ *   - a plan is immutable after creation, so concurrent launches that share a plan are safe.
+ *
+ * Operand layout (what `sparse2Tensor` + `tf.sparse.reorder` produce in the reference,
+ * h2gcn/datasets/_dataset.py:528-535, re-expressed as CSR):
+ *   rowptr  int64 [n_rows+1]   ascending, rowptr[0] == 0
+ *   colidx  int32 [nnz]        ascending inside each row (row-major canonical order), 0 <= col < n_cols
+ *   vals    fp32  [nnz]        the normalised adjacency values (SYM: D^-1/2 A_k D^-1/2, RW: D^-1 A_k;
+ *                              _dataset.py:109-124) -- the kernel is agnostic to how they were normalised.
+ */
+#ifndef H2GCN_HIP_H_
+#define H2GCN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H2GCN_ABI_VERSION 1
+#define H2GCN_MAX_HOPS 8
+
+typedef enum h2gcn_status {
+    H2GCN_OK = 0,
+    H2GCN_ERR_INVALID_ARGUMENT = -1, /* NULL pointer, bad size/stride/alignment, bad hop mask            */
+    H2GCN_ERR_HIP = -2,              /* a HIP runtime call failed (message carries hipGetErrorString)     */
+    H2GCN_ERR_OUT_OF_MEMORY = -3,    /* host or device allocation failed                                  */
+    H2GCN_ERR_BAD_INDEX = -4,        /* rowptr not monotone / colidx out of range (TF: InvalidArgument)   */
+    H2GCN_ERR_NO_TRANSPOSE = -5,     /* adjoint launch on a plan created without H2GCN_PLAN_BUILD_TRANSPOSE */
+    H2GCN_ERR_INTERNAL = -6
+} h2gcn_status;
+
+/* flags for h2gcn_plan_opts.flags */
+#define H2GCN_PLAN_BUILD_TRANSPOSE 0x1u /* also build A_k^T (needed by h2gcn_spmm_hops_T_f32)               */
+#define H2GCN_PLAN_SKIP_VALIDATION 0x2u /* skip the one-time column-range check on the device               */
+
+/* Tunables of the CSR-adaptive schedule.  Zero in a field means "library default". */
+typedef struct h2gcn_plan_opts {
+    uint32_t struct_size;        /* = sizeof(h2gcn_plan_opts), for forward compatibility                   */
+    uint32_t flags;              /* H2GCN_PLAN_*                                                            */
+    int32_t long_row_threshold;  /* (row,hop) segments with >= this many nonzeros are split across the
+                                    waves of one workgroup (LDS-staged partial sums); default 1024         */
+    int32_t rows_per_wave;       /* consecutive rows a wave walks in the regular path; default 4           */
+    int32_t variant;             /* kernel variant selector, 0 = default                   */
+    int32_t reserved[3];
+} h2gcn_plan_opts;
+
+/* Opaque: row-bin tables (long-segment list), optional transposed CSR, launch geometry. */
+typedef struct h2gcn_plan h2gcn_plan_t;
+
+/* ABI version of the loaded library (== H2GCN_ABI_VERSION it was built with). */
+int h2gcn_abi_version(void);
+
+/* Message of the last failure on this thread ("" if none).  Never NULL; valid until the next failing call
+ * on the same thread. */
+const char* h2gcn_last_error(void);
+
+/* Number of HIP devices visible; negative h2gcn_status when the runtime cannot be initialised. */
+int h2gcn_device_count(void);
+
+/*
+ * Build the launch plan for a list of hop matrices A_0..A_{H-1} that share one row space.
+ * Stands in for: the once-per-run construction of `tensors.adj_hops`
+ * (reference h2gcn/datasets/_dataset.py:559-576) as far as the device side is concerned -- the normalised
+ * values themselves are computed by the caller.
+ *
+ *   n_hops            1..H2GCN_MAX_HOPS  (H2GCN uses 2: exact-1-hop and exact-2-hop neighbourhoods)
+ *   n_rows, n_cols    matrix shape; n_rows != n_cols is allowed (row-partitioned shards: n_rows = N/P)
+ *   rowptr_dev[k], colidx_dev[k], vals_dev[k]   CSR of hop k, device pointers (see layout above)
+ *   opts              NULL for defaults
+ *   stream            stream used for the one-time validation / transposition work; the call returns after
+ *                     that work has completed (it synchronises the stream)
+ *
+ * Index validity (monotone rowptr, 0 <= col < n_cols) is checked here, once -- not per launch.  TensorFlow's
+ * CPU kernel reports out-of-range indices as InvalidArgument at run time; this returns H2GCN_ERR_BAD_INDEX.
+ */
+int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols,
+                      const int64_t* const* rowptr_dev, const int32_t* const* colidx_dev,
+                      const float* const* vals_dev, const h2gcn_plan_opts* opts, void* stream,
+                      h2gcn_plan_t** out_plan);
+
+/* Release the plan and everything it owns (never the caller's CSR arrays).  NULL is a no-op. */
+void h2gcn_plan_destroy(h2gcn_plan_t* plan);
+
+/* Introspection (for reports and tests).  Any out pointer may be NULL. */
+int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t* n_cols, int64_t* nnz,
+                    int64_t* n_long_segments, int32_t* has_transpose);
+
+/*
+ * Fused multi-hop aggregation, forward:
+ *
+ *     Y[i*ldy_row + s*ldy_hop + c] = sum_j A_k[i,j] * X[j*ldx + c]      0<=i<n_rows, 0<=c<d
+ *
+ * for every selected hop k (bit k of hop_mask set; s = rank of k among the selected hops, ascending).
+ * Stands in for GCNLayer.call (reference h2gcn/models/_layers.py:78-81): with ldy_hop = d and
+ * ldy_row = H_sel*d the output is the stacked [n_rows, H_sel, d] tensor, already flattened the way the
+ * following `V` (Flatten) layer wants it (h2gcn/models/H2GCN.py:271-272); other strides let the caller land
+ * the hops directly inside a wider concat buffer (ConcatLayer, _layers.py:90-96).
+ * `hop_mask` reproduces GCNLayer(hops=...) (_layers.py:57-59,80-81); 0 means "all hops of the plan".
+ * Rows without nonzeros produce zeros (TF zero-initialises the output).  Offsets are 64-bit throughout:
+ * the reference's column-split workaround for nnz*d > 2^31 (_layers.py:65-74) has no counterpart here.
+ *
+ *   X_dev   fp32, n_cols rows of d values, row stride ldx >= d (elements)
+ *   Y_dev   fp32, must not alias X
+ *   d       feature width >= 1.  Fast paths: d in {32,64,128,256} with 16-byte aligned X/Y and strides that
+ *           are multiples of 4; anything else takes the generic column-tiled path (same results).
+ */
+int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X_dev, int64_t ldx,
+                        int32_t d, float* Y_dev, int64_t ldy_row, int64_t ldy_hop, void* stream);
+
+/*
+ * Adjoint (backward wrt X):
+ *
+ *     dX[j*ldx + c] = sum_s sum_i A_k[i,j] * dY[i*ldg_row + s*ldg_hop + c]   0<=j<n_cols
+ *
+ * Stands in for the TF-registered gradient of SparseTensorDenseMatMul wrt its dense operand
+ * (adjoint_a=True SpMM), summed over the hops that `tf.stack` fanned out, as reached from
+ * tape.gradient (reference h2gcn/models/H2GCN.py:66-74).  The gradient wrt the adjacency values, which TF
+ * also computes and the reference discards, is not computed.  Requires H2GCN_PLAN_BUILD_TRANSPOSE.
+ * dX is overwritten (not accumulated into).
+ */
+int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* dY_dev, int64_t ldg_row,
+                          int64_t ldg_hop, int32_t d, float* dX_dev, int64_t ldx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H2GCN_HIP_H_ */

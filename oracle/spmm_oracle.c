@@ -1,0 +1,114 @@
+/*
+ * spmm_oracle.c -- TEST INFRASTRUCTURE ONLY.  CPU restatement of the arithmetic on H2GCN's hop-aggregation
+ * path, used as the parity checker by tests/, __graft_entry__.smoke() and the `cpu_baseline` leg of bench.py.
+ * Nothing under h2gcn_amd/ may import, link or call this file.
+ *
+ * What it restates
+ *   (a3) TensorFlow's CPU kernel for `tf.sparse.sparse_dense_matmul` (op SparseTensorDenseMatMul), which is
+ *        where the reference's arithmetic for this path lives: call sites h2gcn/models/_layers.py:47,74,76.
+ *        TensorFlow is a third-party dependency of the reference, NOT vendored under /root/reference and not
+ *        installable here (README.md:34 "TensorFlow >= 2.0 (tested on 2.2)", no lock file).  Its published
+ *        CPU algorithm [upstream, recalled]: `out` is zero-initialised; for each stored nonzero, in stored
+ *        order, `out[m, :] += a_val * b[k, :]`, in fp32, single-threaded.  The reference stores nonzeros in
+ *        row-major canonical order (`tf.sparse.reorder`, h2gcn/datasets/_dataset.py:535), so each output row
+ *        accumulates its terms in ascending column order.  -> oracle_spmm_coo_f32 / oracle_spmm_csr_f32.
+ *   (a1) GCNLayer.call, h2gcn/models/_layers.py:78-81: one SpMM per selected hop, `tf.stack(axis=-2)`
+ *        -> oracle_gcn_layer_f32 writes Y[n_rows, H, d].
+ *   (a4) the gradient wrt the dense operand, dX = sum_k A_k^T dY[:, k, :] (adjoint_a SpMM, reached from
+ *        h2gcn/models/H2GCN.py:66-74) -> oracle_gcn_layer_grad_f32.
+ *
+ * PARITY PINNING: the reference has no tests and TensorFlow cannot run here, so the SpMM arithmetic itself is
+ * "parity unpinned" against TensorFlow; it is pinned instead against scipy's csr @ dense in fp32/fp64
+ * (tests/test_oracle.py) and the OPERANDS are pinned against the reference's own preprocessing code imported
+ * in the build container (tests/golden/, made by tests/golden/make_golden.py).
+ *
+ * Build: `make -C oracle` (gcc, -O2, -ffp-contract=off so every term is a separately rounded mul and add;
+ * the *_fma variant uses fmaf to bracket the other possible TF build).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* (a3) COO in stored order -- the literal loop nest of the upstream kernel. */
+void oracle_spmm_coo_f32(int64_t nnz, const int64_t* rows, const int64_t* cols, const float* vals,
+                         const float* b, int64_t ldb, int64_t d, float* out, int64_t ldo, int64_t n_out_rows) {
+    for (int64_t i = 0; i < n_out_rows; ++i) memset(out + i * ldo, 0, (size_t)d * sizeof(float));
+    for (int64_t e = 0; e < nnz; ++e) {
+        const float a = vals[e];
+        const float* br = b + cols[e] * ldb;
+        float* o = out + rows[e] * ldo;
+        for (int64_t c = 0; c < d; ++c) o[c] = o[c] + a * br[c];
+    }
+}
+
+/* Same arithmetic from CSR (row-major canonical COO == CSR order). */
+void oracle_spmm_csr_f32(int64_t n_rows, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                         const float* b, int64_t ldb, int64_t d, float* out, int64_t ldo) {
+    for (int64_t i = 0; i < n_rows; ++i) {
+        float* o = out + i * ldo;
+        memset(o, 0, (size_t)d * sizeof(float));
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            const float a = vals[e];
+            const float* br = b + (int64_t)colidx[e] * ldb;
+            for (int64_t c = 0; c < d; ++c) o[c] = o[c] + a * br[c];
+        }
+    }
+}
+
+/* fused-multiply-add variant (a TF build with FMA enabled would round like this) */
+void oracle_spmm_csr_f32_fma(int64_t n_rows, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                             const float* b, int64_t ldb, int64_t d, float* out, int64_t ldo) {
+    for (int64_t i = 0; i < n_rows; ++i) {
+        float* o = out + i * ldo;
+        memset(o, 0, (size_t)d * sizeof(float));
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            const float a = vals[e];
+            const float* br = b + (int64_t)colidx[e] * ldb;
+            for (int64_t c = 0; c < d; ++c) o[c] = fmaf(a, br[c], o[c]);
+        }
+    }
+}
+
+/* fp64 accumulation of the fp32 operands: the "exact" answer used to bound rounding error. */
+void oracle_spmm_csr_f64acc(int64_t n_rows, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                            const float* b, int64_t ldb, int64_t d, double* out, int64_t ldo) {
+    for (int64_t i = 0; i < n_rows; ++i) {
+        double* o = out + i * ldo;
+        for (int64_t c = 0; c < d; ++c) o[c] = 0.0;
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            const double a = (double)vals[e];
+            const float* br = b + (int64_t)colidx[e] * ldb;
+            for (int64_t c = 0; c < d; ++c) o[c] += a * (double)br[c];
+        }
+    }
+}
+
+/* (a1) GCNLayer.call: Y[i, k, :] = (A_k @ X)[i, :] for the H given hops, stacked on axis -2. */
+void oracle_gcn_layer_f32(int n_hops, int64_t n_rows, const int64_t* const* rowptr, const int32_t* const* colidx,
+                          const float* const* vals, const float* x, int64_t ldx, int64_t d, float* y) {
+    for (int k = 0; k < n_hops; ++k)
+        oracle_spmm_csr_f32(n_rows, rowptr[k], colidx[k], vals[k], x, ldx, d, y + (int64_t)k * d, (int64_t)n_hops * d);
+}
+
+/* (a4) dX[j, :] = sum_k sum_i A_k[i, j] * dY[i, k, :]; accumulation order: hop-major, then row-major stored
+ * order (what unstacking + one adjoint SpMM per hop + add_n gives). */
+void oracle_gcn_layer_grad_f32(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t* const* rowptr,
+                               const int32_t* const* colidx, const float* const* vals, const float* dy, int64_t d,
+                               float* dx) {
+    float* tmp = (float*)malloc((size_t)n_cols * (size_t)d * sizeof(float));
+    for (int64_t i = 0; i < n_cols * d; ++i) dx[i] = 0.f;
+    for (int k = 0; k < n_hops; ++k) {
+        for (int64_t i = 0; i < n_cols * d; ++i) tmp[i] = 0.f;
+        for (int64_t i = 0; i < n_rows; ++i) {
+            const float* g = dy + (i * n_hops + k) * d;
+            for (int64_t e = rowptr[k][i]; e < rowptr[k][i + 1]; ++e) {
+                const float a = vals[k][e];
+                float* o = tmp + (int64_t)colidx[k][e] * d;
+                for (int64_t c = 0; c < d; ++c) o[c] = o[c] + a * g[c];
+            }
+        }
+        for (int64_t i = 0; i < n_cols * d; ++i) dx[i] = dx[i] + tmp[i];
+    }
+    free(tmp);
+}

@@ -1,0 +1,68 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_artifacts():
+    """CPU-side artefacts the suites need: the oracle's C library and (if absent) the HIP library.
+    Building the checker is not using it; on the GPU box both are already in the snapshot."""
+    import subprocess
+
+    if not (ROOT / "oracle" / "_build" / "liboracle.so").exists():
+        subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
+    if not (ROOT / "h2gcn_amd" / "csrc" / "libh2gcn_hip.so").exists():
+        subprocess.run(["make", "-C", str(ROOT / "h2gcn_amd" / "csrc")], check=True, capture_output=True)
+    yield
+
+
+def load_planetoid_golden(name):
+    """dict of scipy CSR matrices / arrays from tests/golden/<name>_operands.npz."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    z = np.load(GOLDEN / f"{name}_operands.npz")
+    n = len(z["adj_raw_indptr"]) - 1
+
+    def csr(prefix, data_key=None, idx_prefix=None, shape=None):
+        ip = z[f"{idx_prefix or prefix}_indptr"]
+        ix = z[f"{idx_prefix or prefix}_indices"]
+        da = z[data_key or f"{prefix}_data"]
+        return sp.csr_matrix((da, ix, ip), shape=shape or (n, n))
+
+    nfeat = int(z["feat_raw_indices"].max()) + 1
+    out = dict(
+        n=n,
+        adj_raw=csr("adj_raw"),
+        adj_noeye=csr("adj_noeye"),
+        feat_raw=csr("feat_raw", shape=(n, nfeat)).astype(str(z["feat_raw_dtype"])),
+        feat_rownorm=csr("feat_rownorm", data_key="feat_rownorm_data", idx_prefix="feat_raw", shape=(n, nfeat)),
+        hop1_sym=csr("hop1_sym"), hop2_sym=csr("hop2_sym"),
+        hop1_rw=csr("hop1_rw", data_key="hop1_rw_data", idx_prefix="hop1_sym"),
+        hop2_rw=csr("hop2_rw", data_key="hop2_rw_data", idx_prefix="hop2_sym"),
+        hop01_sym=csr("hop01_sym"),
+        split_nnz=z["split_nnz"], y_all=z["y_all"], train_mask=z["train_mask"], val_mask=z["val_mask"],
+        test_mask=z["test_mask"], num_labels=int(z["num_labels"]),
+    )
+    return out
+
+
+def load_syn_products_golden():
+    import numpy as np
+    import scipy.sparse as sp
+
+    z = np.load(GOLDEN / "syn_products.npz")
+    n = len(z["indptr"]) - 1
+    a = sp.csr_matrix((np.ones(len(z["indices"]), dtype=np.float32), z["indices"], z["indptr"]), shape=(n, n))
+    return a, z["labels"], float(z["homophily"])

@@ -1,0 +1,83 @@
+"""CPU suite: the N > 1 path -- row partitioning + per-layer all-gather -- with world_size-2/3 gloo processes.
+The SpMM itself is replaced by the oracle here (no GPU); what is under test is the partition logic and the
+collective plumbing that bench.py and the multi-GPU path use."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_block_bounds_cover_rows_exactly():
+    from h2gcn_amd.partition import block_bounds, rows_per_rank
+
+    for n in (0, 1, 7, 8, 9, 2_400_000, 170_000):
+        for P in (1, 2, 3, 4, 8):
+            b = [block_bounds(n, P, p) for p in range(P)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(P - 1))
+            assert all(0 <= r1 - r0 <= rows_per_rank(n, P) for r0, r1 in b)
+    with pytest.raises(ValueError):
+        block_bounds(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, d, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import scipy.sparse as sp
+
+        from h2gcn_amd import synth
+        from h2gcn_amd.partition import EmbeddingAllGather, block_bounds, shard_rows_scipy
+        from oracle import gcn_layer as og
+
+        r0, r1 = block_bounds(n, world, rank)
+        degs = [synth.synth_degrees(n, 20 * n, s, n) for s in (1, 2)]
+        # each rank generates ONLY its own shard of operands and features
+        shard = []
+        for k, s in enumerate((1, 2)):
+            rp, ci, va = synth.synth_hop_rows_np(degs[k], n, s, r0, r1)
+            shard.append(sp.csr_matrix((va, ci, rp), shape=(r1 - r0, n)))
+        x_local = torch.from_numpy(synth.synth_features_np(d, 3, r0, r1))
+        ag = EmbeddingAllGather(n, d, "cpu")
+        x_full = ag.gather(x_local)
+        assert x_full.shape == (n, d)
+        assert np.array_equal(x_full.numpy(), synth.synth_features_np(d, 3, 0, n))  # gathered == global
+        y_local = og.gcn_layer_c(shard, x_full.numpy())
+        np.save(Path(out_dir) / f"y{rank}.npy", y_local)
+        if rank == 0:  # single-process answer on the unpartitioned operands
+            full = []
+            for k, s in enumerate((1, 2)):
+                rp, ci, va = synth.synth_hop_rows_np(degs[k], n, s, 0, n)
+                full.append(sp.csr_matrix((va, ci, rp), shape=(n, n)))
+            np.save(Path(out_dir) / "full.npy", og.gcn_layer_c(full, x_full.numpy()))
+            assert all(m.shape[0] == block_bounds(n, world, p)[1] - block_bounds(n, world, p)[0]
+                       for p in range(world) for m in shard_rows_scipy(full, world, p)[:1])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 1000), (3, 1001)])
+def test_row_partition_allgather_equals_single_rank(world, n, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, 16, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"y{r}.npy") for r in range(world)]
+    full = np.load(tmp_path / "full.npy")
+    assert np.array_equal(np.concatenate(parts, 0), full)  # bit-for-bit: partitioning never changes arithmetic

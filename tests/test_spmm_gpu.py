@@ -1,0 +1,337 @@
+"""GPU suite: the HIP hop aggregation (through the C ABI) against the CPU oracle.
+
+Tolerance: BASELINE.json's north star asks for layer outputs within 1e-5 of the reference in fp32.  ATOL below
+is that 1e-5 (absolute, on outputs whose magnitude is O(1) or smaller); the only arithmetic difference between
+the kernel and the oracle's sequential loop is the association order of the per-row sum (2-4 interleaved lane
+groups, 4 waves for long rows) and fused multiply-add.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import load_planetoid_golden, load_syn_products_golden
+from oracle import gcn_layer as og
+from oracle import operands as oo
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU suite needs a GPU"
+    return torch.device("cuda:0")
+
+
+def run_hip(hops, x, **kw):
+    from h2gcn_amd import HopPlan
+
+    spmm_kw = {k: kw.pop(k) for k in ("hops_sel",) if k in kw}
+    plan = HopPlan.from_scipy(hops, dev(), **kw)
+    y = plan.spmm(torch.from_numpy(np.ascontiguousarray(x)).to(dev()), hops=spmm_kw.get("hops_sel"))
+    torch.cuda.synchronize()
+    return y.cpu().numpy(), plan
+
+
+def rand_csr(n_rows, n_cols, density, seed, empty_frac=0.0):
+    rng = np.random.default_rng(seed)
+    m = sp.random(n_rows, n_cols, density, format="csr", random_state=seed, dtype=np.float32)
+    m.data = rng.uniform(-1, 1, m.nnz).astype(np.float32)
+    if empty_frac:
+        keep = rng.random(n_rows) >= empty_frac
+        m = sp.diags(keep.astype(np.float32)) @ m
+        m.eliminate_zeros()
+    m = sp.csr_matrix(m)
+    m.sort_indices()
+    return m
+
+
+# ----------------------------------------------------------------------------- golden graphs (configs 1, 2)
+@pytest.mark.parametrize("norm", ["sym", "rw"])
+@pytest.mark.parametrize("d", [64, 128])
+def test_cora_golden_operands(d, norm):
+    g = load_planetoid_golden("cora")
+    hops = [g[f"hop1_{norm}"], g[f"hop2_{norm}"]]
+    x = np.random.Generator(np.random.PCG64(123)).uniform(-1, 1, (g["n"], d)).astype(np.float32)
+    y, _ = run_hip(hops, x)
+    want = og.gcn_layer_c(hops, x)
+    assert y.shape == (g["n"], 2, d)
+    assert np.abs(y - want).max() <= ATOL
+    assert np.abs(y - og.gcn_layer_f64acc(hops, x)).max() <= ATOL
+    # rows with no 2-hop neighbours are exactly zero (TF zero-initialises)
+    empty = np.diff(hops[1].indptr) == 0
+    assert empty.sum() == 141 and not y[empty, 1, :].any()
+
+
+def test_cora_two_stacked_layers_r1_r2():
+    """r1 = [A1 r0 | A2 r0], r2 = [A1 r1 | A2 r1] of H2GCN-2 (reference H2GCN.py:294-346)."""
+    from h2gcn_amd import GCNLayer, HopPlan
+
+    g = load_planetoid_golden("cora")
+    hops = [g["hop1_sym"], g["hop2_sym"]]
+    r0 = np.abs(np.random.Generator(np.random.PCG64(7)).standard_normal((g["n"], 64))).astype(np.float32)
+    plan = HopPlan.from_scipy(hops, dev())
+    layer = GCNLayer()
+    r1 = layer(plan, torch.from_numpy(r0).to(dev())).flatten(1)
+    r2 = layer(plan, r1).flatten(1)
+    w1 = og.gcn_layer_c(hops, r0).reshape(g["n"], 128)
+    w2 = og.gcn_layer_c(hops, w1).reshape(g["n"], 256)
+    assert np.abs(r1.cpu().numpy() - w1).max() <= ATOL
+    assert np.abs(r2.cpu().numpy() - w2).max() <= ATOL
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_syn_products_fixture(d):
+    """BASELINE.json configs[1]: syn-products h=0.2, |V|=10k -- graph from the reference generator, exact 2-hop
+    ring from the oracle's nhoodSplit restatement, SYM norm, H2GCN-2 widths 64 and 128."""
+    a, labels, _ = load_syn_products_golden()
+    hops = oo.adj_norm_hops(oo.remove_eye(a), ("1", "2"), oo.SYM)
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((10000, d)) + labels[:, None] * 0.1).astype(np.float32)  # class-conditional
+    y, plan = run_hip(hops, x)
+    want = og.gcn_layer_c(hops, x)
+    assert np.abs(y - want).max() <= ATOL
+    assert plan.info(1)["nnz"] == hops[1].nnz
+
+
+# ----------------------------------------------------------------------------- adversarial shapes
+@pytest.mark.parametrize("d", [1, 3, 4, 32, 64, 100, 128, 132, 200, 256, 260, 448])
+def test_feature_widths(d):
+    hops = [rand_csr(301, 301, 0.05, 1, empty_frac=0.1), rand_csr(301, 301, 0.15, 2, empty_frac=0.3)]
+    x = np.random.default_rng(d).uniform(-1, 1, (301, d)).astype(np.float32)
+    y, _ = run_hip(hops, x)
+    assert np.abs(y - og.gcn_layer_f64acc(hops, x)).max() <= ATOL
+
+
+@pytest.mark.parametrize("n_rows,n_cols", [(1, 1), (5, 9), (63, 64), (64, 63), (65, 1000), (1000, 17), (4097, 333)])
+def test_ragged_shapes_rectangular(n_rows, n_cols):
+    hops = [rand_csr(n_rows, n_cols, 0.3, 3), rand_csr(n_rows, n_cols, 0.6, 4, empty_frac=0.2)]
+    x = np.random.default_rng(0).uniform(-1, 1, (n_cols, 128)).astype(np.float32)
+    y, _ = run_hip(hops, x)
+    assert y.shape == (n_rows, 2, 128)
+    assert np.abs(y - og.gcn_layer_f64acc(hops, x)).max() <= ATOL
+
+
+def test_all_empty_and_zero_nnz():
+    hops = [sp.csr_matrix((50, 50), dtype=np.float32), sp.csr_matrix((50, 50), dtype=np.float32)]
+    x = np.ones((50, 128), dtype=np.float32)
+    y, _ = run_hip(hops, x)
+    assert y.shape == (50, 2, 128) and not y.any()
+
+
+@pytest.mark.parametrize("d", [64, 128, 100])
+@pytest.mark.parametrize("threshold", [0, 8, 64, 70])
+def test_long_rows_split_across_the_workgroup(d, threshold):
+    """One huge row (5000 nnz), a few medium ones, many short: exercises the LDS-staged long-segment path
+    (threshold 0 = library default 1024; small thresholds push most rows through it)."""
+    rng = np.random.default_rng(9)
+    n = 6000
+    deg = rng.integers(0, 12, n)
+    deg[17] = 5000
+    deg[n - 1] = 1500
+    deg[100:110] = 65
+    rows = np.repeat(np.arange(n), deg)
+    cols = np.concatenate([rng.choice(n, k, replace=False) for k in deg])
+    a1 = sp.csr_matrix((rng.uniform(-1, 1, len(rows)).astype(np.float32), (rows, cols)), shape=(n, n))
+    a1.sort_indices()
+    a2 = rand_csr(n, n, 0.002, 5)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    y, plan = run_hip([a1, a2], x, long_row_threshold=threshold)
+    want = og.gcn_layer_f64acc([a1, a2], x)
+    assert np.abs(y - want).max() <= 2e-5  # 5000-term sums of O(1) terms: fp32 roundoff of the sum itself ~1e-5
+    if threshold == 0:
+        assert plan.info(0)["n_long_segments"] == 2 and plan.info(1)["n_long_segments"] == 0
+
+
+@pytest.mark.parametrize("rpw", [1, 2, 3, 7])
+def test_rows_per_wave_does_not_change_results(rpw):
+    hops = [rand_csr(777, 777, 0.05, 1, empty_frac=0.1), rand_csr(777, 777, 0.1, 2)]
+    x = np.random.default_rng(1).uniform(-1, 1, (777, 128)).astype(np.float32)
+    y0, _ = run_hip(hops, x)
+    y1, _ = run_hip(hops, x, rows_per_wave=rpw)
+    assert np.array_equal(y0, y1)  # geometry never changes the arithmetic
+
+
+def test_variant_scalar_addressing_matches():
+    hops = [rand_csr(500, 500, 0.1, 1), rand_csr(500, 500, 0.2, 2)]
+    x = np.random.default_rng(1).uniform(-1, 1, (500, 128)).astype(np.float32)
+    y1, _ = run_hip(hops, x, variant=1)
+    assert np.abs(y1 - og.gcn_layer_f64acc(hops, x)).max() <= ATOL
+
+
+def test_padding_never_touches_x():
+    """No nonzero points at column 0, whose feature row is Inf/NaN: results must stay finite -- i.e. padded
+    gather slots are predicated off, not multiplied by zero."""
+    rng = np.random.default_rng(3)
+    n = 400
+    m = rand_csr(n, n, 0.08, 6).tolil()
+    m[:, 0] = 0
+    m = sp.csr_matrix(m)
+    m.eliminate_zeros()
+    x = rng.uniform(-1, 1, (n, 128)).astype(np.float32)
+    x[0, :64] = np.inf
+    x[0, 64:] = np.nan
+    for d in (128, 100, 64):
+        y, _ = run_hip([m, m], x[:, :d].copy())
+        assert np.isfinite(y).all()
+
+
+def test_hop_selection_and_strided_output():
+    """GCNLayer(hops={1}) (reference _layers.py:57-59,80-81) and writing into a slice of a wider buffer."""
+    from h2gcn_amd import GCNLayer, HopPlan
+
+    hops = [rand_csr(300, 300, 0.05, 1), rand_csr(300, 300, 0.1, 2), rand_csr(300, 300, 0.02, 3)]
+    x = np.random.default_rng(1).uniform(-1, 1, (300, 64)).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev())
+    plan = HopPlan.from_scipy(hops, dev())
+    want = og.gcn_layer_f64acc(hops, x)
+    y = GCNLayer(hops={1})(plan, xt)
+    assert y.shape == (300, 1, 64) and np.abs(y.cpu().numpy()[:, 0] - want[:, 1]).max() <= ATOL
+    y = GCNLayer(hops={0, 2, 9})(plan, xt)  # unknown index 9 is ignored like the reference's filter
+    assert np.abs(y.cpu().numpy() - want[:, [0, 2]]).max() <= ATOL
+    with pytest.raises(ValueError):
+        GCNLayer(hops={7})(plan, xt)
+    # land the three hops in columns [64, 256) of a [300, 320] concat buffer, strided input
+    buf = torch.full((300, 320), -7.0, device=dev())
+    xwide = torch.zeros((300, 96), device=dev())
+    xwide[:, :64] = xt
+    plan.spmm(xwide[:, :64], out=buf[:, 64:256].view(300, 3, 64))
+    b = buf.cpu().numpy()
+    assert np.abs(b[:, 64:256].reshape(300, 3, 64) - want).max() <= ATOL
+    assert (b[:, :64] == -7).all() and (b[:, 256:] == -7).all()
+
+
+# ----------------------------------------------------------------------------- adjoint / autograd
+@pytest.mark.parametrize("d", [64, 128, 100])
+def test_adjoint_matches_oracle(d):
+    from h2gcn_amd import HopPlan
+
+    hops = [rand_csr(700, 500, 0.05, 1, empty_frac=0.1), rand_csr(700, 500, 0.1, 2)]
+    dy = np.random.default_rng(2).uniform(-1, 1, (700, 2, d)).astype(np.float32)
+    plan = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=16)
+    dx = plan.spmm_t(torch.from_numpy(dy).to(dev())).cpu().numpy()
+    want = og.gcn_layer_grad_c(hops, dy, 500)
+    assert dx.shape == (500, d)
+    assert np.abs(dx - want).max() <= 2e-5
+    dx1 = plan.spmm_t(torch.from_numpy(dy[:, 1:2].copy()).to(dev()), hops=[1]).cpu().numpy()
+    assert np.abs(dx1 - og.gcn_layer_grad_c(hops[1:], dy[:, 1:2].copy(), 500)).max() <= 2e-5
+
+
+def test_autograd_through_gcn_layer():
+    from h2gcn_amd import GCNLayer, HopPlan
+
+    g = load_planetoid_golden("cora")
+    hops = [g["hop1_sym"], g["hop2_sym"]]
+    plan = HopPlan.from_scipy(hops, dev(), build_transpose=True)
+    x = torch.randn(g["n"], 64, device=dev(), requires_grad=True)
+    w = torch.randn(g["n"], 2, 64, device=dev())
+    (GCNLayer()(plan, x) * w).sum().backward()
+    want = og.gcn_layer_grad_c(hops, w.cpu().numpy(), g["n"])
+    assert np.abs(x.grad.cpu().numpy() - want).max() <= 2e-5
+    # A is symmetric under SYM normalisation on an undirected graph: adjoint == forward applied per hop
+    y = plan.spmm(w[:, 0].contiguous())[:, 0] + plan.spmm(w[:, 1].contiguous())[:, 1]
+    assert (y - x.grad).abs().max().item() <= 2e-5
+    plan_nt = HopPlan.from_scipy(hops, dev())
+    x2 = torch.randn(g["n"], 64, device=dev(), requires_grad=True)
+    with pytest.raises(ValueError, match="build_transpose"):
+        GCNLayer()(plan_nt, x2).sum().backward()
+
+
+# ----------------------------------------------------------------------------- determinism / partitioning
+def test_bitwise_repeatable_and_row_partition_invariant():
+    """a row-partitioned run must equal the single-GPU run bit-for-bit."""
+    from h2gcn_amd import HopPlan
+
+    hops = [rand_csr(2001, 2001, 0.02, 1, empty_frac=0.05), rand_csr(2001, 2001, 0.05, 2)]
+    hops[0] = sp.csr_matrix(sp.vstack([hops[0][:5], sp.csr_matrix(np.ones((1, 2001), dtype=np.float32) / 2001), hops[0][6:]]))
+    x = np.random.default_rng(1).uniform(-1, 1, (2001, 128)).astype(np.float32)
+    full, _ = run_hip(hops, x, long_row_threshold=256)
+    again, _ = run_hip(hops, x, long_row_threshold=256)
+    assert np.array_equal(full, again)
+    for P in (2, 3, 8):
+        bounds = np.linspace(0, 2001, P + 1).astype(int)
+        parts = []
+        for p in range(P):
+            shard = [h[bounds[p]:bounds[p + 1]] for h in hops]
+            yp, _ = run_hip(shard, x, long_row_threshold=256)
+            parts.append(yp)
+        assert np.array_equal(np.concatenate(parts, 0), full)
+
+
+# ----------------------------------------------------------------------------- error behaviour
+def test_errors_are_python_exceptions_before_or_at_the_c_call():
+    from h2gcn_amd import HopPlan, _capi
+
+    d = dev()
+    m = rand_csr(10, 10, 0.3, 1)
+    plan = HopPlan.from_scipy([m], d)
+    with pytest.raises(ValueError):
+        plan.spmm(torch.zeros(11, 4, device=d))           # wrong row count
+    with pytest.raises(ValueError):
+        plan.spmm(torch.zeros(10, 4, device=d, dtype=torch.float64))
+    with pytest.raises(ValueError):
+        plan.spmm(torch.zeros(10, 4))                      # CPU tensor
+    with pytest.raises(ValueError):
+        plan.spmm_t(torch.zeros(10, 1, 4, device=d))       # no transpose built
+    rp = torch.tensor([0, 2, 1], dtype=torch.int64, device=d)
+    ci = torch.tensor([0, 1], dtype=torch.int32, device=d)
+    va = torch.ones(2, device=d)
+    with pytest.raises(_capi.H2GCNError) as e:
+        HopPlan([rp], [ci], [va], 2)
+    assert e.value.status == _capi.ERR_BAD_INDEX
+    rp = torch.tensor([0, 1, 2], dtype=torch.int64, device=d)
+    ci = torch.tensor([0, 5], dtype=torch.int32, device=d)
+    with pytest.raises(_capi.H2GCNError) as e:
+        HopPlan([rp], [ci], [va], 2)                       # column 5 out of range (TF: InvalidArgument)
+    assert e.value.status == _capi.ERR_BAD_INDEX
+
+
+# ----------------------------------------------------------------------------- BASELINE shapes, size-independent properties
+@pytest.mark.parametrize("shape", ["arxiv", "products"])
+def test_baseline_shapes_properties(shape):
+    """configs[2] / configs[3] at FULL size: (1) row-stochastic hops map the all-ones features to ones on every
+    non-empty row and zeros on empty rows; (2) linearity; (3) sampled rows against the fp64 oracle, the CPU
+    regenerating those rows of the operands independently (counter-based generator)."""
+    from h2gcn_amd import HopPlan, synth
+
+    cfg = synth.SHAPES[shape]
+    n, d = cfg["n"], cfg["d"]
+    device = dev()
+    degs = [synth.synth_degrees(n, cfg["nnz_per_hop"], s, n) for s in (synth.SEED_A1, synth.SEED_A2)]
+    csr = [synth.synth_hop_rows(degs[k], n, (synth.SEED_A1, synth.SEED_A2)[k], 0, n, device) for k in range(2)]
+    plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n)
+    nnz = plan.nnz
+    assert all(abs(z - cfg["nnz_per_hop"]) < 0.01 * cfg["nnz_per_hop"] for z in nnz)
+    x = synth.synth_features(d, synth.SEED_X, 0, n, device)
+    y = plan.spmm(x)
+    # (1) row-stochastic
+    ones = torch.ones((n, d), device=device)
+    y1 = plan.spmm(ones)
+    for k in range(2):
+        nonempty = (csr[k][0][1:] - csr[k][0][:-1]) > 0
+        assert (y1[nonempty, k] - 1).abs().max().item() <= 1e-4  # sum of deg copies of fl(1/deg), deg up to 17k
+        assert not y1[~nonempty, k].any().item()
+    # (2) linearity: A(2x + 1) == 2 A x + A 1
+    y2 = plan.spmm(2 * x + ones)
+    assert (y2 - (2 * y + y1)).abs().max().item() <= 1e-4
+    del y1, y2, ones
+    # (3) sampled rows vs the oracle on independently regenerated operands
+    rng = np.random.default_rng(0)
+    blocks = [0, n - 8] + list(rng.integers(0, n - 8, 6))
+    longest = int(np.argmax(degs[0]))
+    blocks.append(min(longest, n - 8))
+    for r0 in blocks:
+        r0 = int(r0)
+        parts = []
+        for k, seed in enumerate((synth.SEED_A1, synth.SEED_A2)):
+            rp, ci, va = synth.synth_hop_rows_np(degs[k], n, seed, r0, r0 + 8)
+            lo, hi = int(csr[k][0][r0]), int(csr[k][0][r0 + 8])
+            assert np.array_equal(ci, csr[k][1][lo:hi].cpu().numpy())  # GPU-built CSR == CPU-built CSR
+            parts.append((rp, ci, va))
+        cols = np.unique(np.concatenate([p[1] for p in parts]))
+        xs = x[torch.from_numpy(cols.astype(np.int64)).to(device)].cpu().numpy()
+        remap = {c: i for i, c in enumerate(cols)}
+        local = [(p[0], np.array([remap[c] for c in p[1]], dtype=np.int32), p[2]) for p in parts]
+        want = og.rows_subset(local, xs, list(range(8)))
+        got = y[r0:r0 + 8].cpu().numpy()
+        assert np.abs(got - want).max() <= ATOL

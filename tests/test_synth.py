@@ -1,0 +1,52 @@
+"""CPU suite: the synthetic-operand generator (bench inputs) -- numpy and torch paths are bit-identical and any
+row block can be generated independently (what row-partitioned ranks rely on)."""
+import numpy as np
+import torch
+
+from h2gcn_amd import synth
+
+
+def test_splitmix_bits_agree():
+    x = np.arange(0, 5000, dtype=np.uint64) * np.uint64(0x123456789) + np.uint64(2**63 - 5)
+    a = synth.splitmix64_np(x)
+    b = synth.splitmix64_torch(torch.from_numpy(x.view(np.int64)))
+    assert np.array_equal(a.view(np.int64), b.numpy())
+    assert int(synth.splitmix64_np(np.array([0], dtype=np.uint64))[0]) == 0xE220A8397B1DCDAF  # published splitmix64 KAT
+
+
+def test_degrees_shape():
+    n = 20000
+    deg = synth.synth_degrees(n, 1_000_000, 123, n)
+    assert abs(int(deg.sum()) - 1_000_000) < 0.01 * 1_000_000
+    assert 0.005 < (deg == 0).mean() < 0.02
+    assert deg.max() > 20 * np.median(deg[deg > 0])  # heavy tail
+    assert np.array_equal(deg, synth.synth_degrees(n, 1_000_000, 123, n))
+
+
+def test_numpy_torch_identical_and_block_decomposable():
+    n = 3000
+    deg = synth.synth_degrees(n, 60000, 124, n)
+    full = synth.synth_hop_rows_np(deg, n, 124, 0, n)
+    t = synth.synth_hop_rows(deg, n, 124, 0, n, "cpu")
+    for a, b in zip(full, t):
+        assert np.array_equal(a, b.numpy())
+    rp, ci, va = full
+    assert rp.dtype == np.int64 and ci.dtype == np.int32 and va.dtype == np.float32
+    for r in range(0, n, 97):  # sorted, unique, in range, 1/deg values
+        seg = ci[rp[r]:rp[r + 1]]
+        assert np.all(np.diff(seg) > 0) and (len(seg) == 0 or (seg.min() >= 0 and seg.max() < n))
+        if len(seg):
+            assert np.all(va[rp[r]:rp[r + 1]] == np.float32(1) / np.float32(len(seg)))
+    # a block generated alone equals the slice of the full matrix
+    r0, r1 = 700, 1900
+    brp, bci, bva = synth.synth_hop_rows_np(deg, n, 124, r0, r1)
+    assert np.array_equal(brp, rp[r0:r1 + 1] - rp[r0])
+    assert np.array_equal(bci, ci[rp[r0]:rp[r1]]) and np.array_equal(bva, va[rp[r0]:rp[r1]])
+
+
+def test_features_identical_and_uniform():
+    a = synth.synth_features_np(128, 125, 10, 210)
+    b = synth.synth_features(128, 125, 10, 210, "cpu").numpy()
+    assert np.array_equal(a, b) and a.dtype == np.float32
+    assert -1 <= a.min() and a.max() < 1 and abs(a.mean()) < 0.02
+    assert np.array_equal(synth.synth_features_np(128, 125, 0, 300)[10:210], a)
