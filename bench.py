@@ -34,6 +34,19 @@ def algorithmic_bytes(nnz_list, n_rows_out, d, n_hops):
     return sum(z * (4 + 4 + 4 * d) + (n_rows_out + 1) * 8 for z in nnz_list) + n_rows_out * n_hops * d * 4
 
 
+def pmc_traffic(shape, d, chunks, slice_cols, world):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    see profiles/*_summary.json); bench.py cannot collect counters itself, so this is null for any
+    configuration that has not been profiled."""
+    try:
+        table = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+    except Exception:
+        return None
+    key = f"{shape}|d={d}|chunks={chunks}|slice={slice_cols or 'auto'}|gpus={world}"
+    e = table.get(key)
+    return None if e is None else e.get("bytes_per_launch")
+
+
 def cpu_baseline(plan_csr, x_full, d, target_seconds=12.0):
     """Reported baseline (NOT the target): the plain-C oracle port of the reference's CPU arithmetic, 1 thread
     (TF's CPU SparseTensorDenseMatMul is single-threaded), on a bounded row sample of the SAME operands."""
@@ -83,6 +96,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--long-row-threshold", type=int, default=0)
     ap.add_argument("--rows-per-wave", type=int, default=0)
+    ap.add_argument("--slice-cols", type=int, default=0, help="feature columns per slice (0 = library heuristic)")
+    ap.add_argument("--chunks", type=int, default=-1,
+                    help="feature chunks of the pipelined all-gather/SpMM (default: 1 on one GPU, 4 on several)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
@@ -103,7 +119,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from h2gcn_amd import HopPlan, synth
-    from h2gcn_amd.partition import EmbeddingAllGather, block_bounds
+    from h2gcn_amd.partition import PipelinedHopAggregation, block_bounds
 
     cfg = synth.SHAPES[a.shape]
     n, d = cfg["n"], (a.d or cfg["d"])
@@ -113,9 +129,11 @@ def main():
     csr = [synth.synth_hop_rows(degs[k], n, seeds[k], r0, r1, device) for k in range(2)]
     torch.cuda.synchronize()
     plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n,
-                   variant=a.variant, long_row_threshold=a.long_row_threshold, rows_per_wave=a.rows_per_wave)
+                   variant=a.variant, long_row_threshold=a.long_row_threshold, rows_per_wave=a.rows_per_wave,
+                   slice_cols=a.slice_cols)
     x_local = synth.synth_features(d, synth.SEED_X, r0, r1, device)
-    gatherer = EmbeddingAllGather(n, d, device)
+    chunks = a.chunks if a.chunks > 0 else (1 if world == 1 else 4)
+    layer = PipelinedHopAggregation(plan, n, d, chunks, device)
     y = torch.empty((r1 - r0, 2, d), dtype=torch.float32, device=device)
     nnz_local = plan.nnz
     nnz_t = torch.tensor(nnz_local, dtype=torch.int64, device=device)
@@ -123,13 +141,9 @@ def main():
         dist.all_reduce(nnz_t)
     nnz_global = [int(v) for v in nnz_t.tolist()]
 
-    def step():
-        x_full = gatherer.gather(x_local)
-        plan.spmm(x_full, out=y)
-
     for _ in range(a.warmup):
-        step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        layer(x_local, out=y)
+    layer.kernel_events = []   # HIP events around every SpMM launch, on the stream it is launched on
 
     def barrier():
         if world > 1:
@@ -139,17 +153,15 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        x_full = gatherer.gather(x_local)
-        ev[i][0].record()          # torch's current stream == the stream the kernel is launched on
-        plan.spmm(x_full, out=y)
-        ev[i][1].record()
+        layer(x_local, out=y)      # [staging + all-gather chunks on the side stream] + `chunks` fused SpMM launches
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    # per-step kernel time = sum over the step's `chunks` launches (one launch when chunks == 1)
+    kern_ms = float(np.sum([s.elapsed_time(e) for s, e in layer.kernel_events])) / a.steps
     kt = torch.tensor([kern_ms], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
@@ -176,13 +188,13 @@ def main():
                           "row-normalised values 1/deg, 2-hop CSR supplied (not derived)",
             "n_rows": n, "nnz_per_hop": nnz_global, "d": d,
             "parallelism": f"row-partition x{world}" + (", RCCL all-gather of X per step" if world > 1 else ""),
-            "kernel_variant": a.variant,
+            "kernel_variant": a.variant, "feature_chunks": chunks, "slice_cols": a.slice_cols or "auto",
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
-            "kernel": "h2gcn::spmm_hops_kernel (fused 1+2-hop)",
+            "traffic": pmc_traffic(a.shape, d, chunks, a.slice_cols, world),
+            "kernel": "h2gcn::spmm_hops_kernel (fused 1+2-hop)" + (f", {chunks} launches of d/{chunks} columns" if chunks > 1 else ""),
             "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_max,
             "algorithmic_bytes_per_launch": b_alg,
         },

@@ -45,7 +45,8 @@ class PlanOpts(C.Structure):
         ("long_row_threshold", C.c_int32),
         ("rows_per_wave", C.c_int32),
         ("variant", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("slice_cols", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 

@@ -76,6 +76,7 @@ struct h2gcn_plan {
     int long_threshold = 1024;
     int rows_per_wave = 4;
     int variant = 0;
+    int slice_cols = 0;  // 0 = heuristic
     bool has_transpose = false;
     int device = 0;
     std::vector<HopOperand> fwd;  // A_k       [n_rows x n_cols], caller-owned arrays
@@ -167,24 +168,51 @@ int get_long_list(const h2gcn_plan* plan, bool adjoint, uint32_t mask, const int
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Column-slice width of the EXACT kernels: the largest fast width that divides d, capped so that the gather
+// working set of one slice (n_src_rows * slice * 4 B) is friendlier to the 256 MiB Infinity Cache when the whole
+// operand is far beyond it.  `forced` > 0 (plan option) overrides the heuristic.
+int pick_slice_cols(int d, int64_t n_src_rows, int forced) {
+    static const int widths[] = {256, 128, 64, 32};
+    if (forced > 0 && d % forced == 0) return forced;  // a forced width that does not divide d falls back to the heuristic
+    int best = 0;
+    for (int w : widths) {
+        if (d % w != 0) continue;
+        if (best == 0) best = w;
+        const double slice_bytes = (double)n_src_rows * w * 4.0;
+        if (w >= 64 && slice_bytes > 768.0 * 1024 * 1024 && d % (w / 2) == 0) continue;  // prefer a narrower slice
+        return w;
+    }
+    return best;
+}
+
 template <bool SUM>
-int launch(const LaunchParams& p, int variant, bool vec_ok, hipStream_t stream) {
+int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_slice, int64_t n_src_rows, hipStream_t stream) {
     using namespace h2gcn;
-    const int64_t n_blocks = (int64_t)p.n_long + p.tiles_per_xcd * kNumXcd;
+    const int slice = (vec_ok && variant != 1) ? pick_slice_cols(p.d, n_src_rows, forced_slice) : 0;
+    const bool exact = slice > 0 || (vec_ok && variant == 1 && p.d == 128);
+    p.slice_cols = exact ? (slice > 0 ? slice : 128) : p.d;
+    p.n_slices = exact ? p.d / p.slice_cols : 1;
+    p.blocks_per_slice = (int64_t)p.n_long + p.tiles_per_xcd * kNumXcd;
+    const int64_t n_blocks = p.blocks_per_slice * p.n_slices;
     if (n_blocks <= 0) return H2GCN_OK;
     if (n_blocks > 0x7fffffffLL) return fail(H2GCN_ERR_INVALID_ARGUMENT, "grid too large (%lld blocks)", (long long)n_blocks);
     const dim3 grid((unsigned)n_blocks), block(kBlock);
-#define H2GCN_LAUNCH(VEC, LPR, EXACT) \
-    hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM>), grid, block, 0, stream, p)
-    if (vec_ok && variant == 1 && p.d == 128) {
+#define H2GCN_LAUNCH(VEC, LPR, EXACT)                                                                      \
+    do {                                                                                                   \
+        if (off32)                                                                                         \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, true>), grid, block, 0, stream, p);  \
+        else                                                                                               \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, false>), grid, block, 0, stream, p); \
+    } while (0)
+    if (exact && variant == 1 && slice == 0) {
         H2GCN_LAUNCH(2, 64, true);  // one neighbour per load instruction, scalar base addressing
-    } else if (vec_ok && p.d == 256) {
+    } else if (slice == 256) {
         H2GCN_LAUNCH(4, 64, true);
-    } else if (vec_ok && p.d == 128) {
+    } else if (slice == 128) {
         H2GCN_LAUNCH(4, 32, true);
-    } else if (vec_ok && p.d == 64) {
+    } else if (slice == 64) {
         H2GCN_LAUNCH(4, 16, true);
-    } else if (vec_ok && p.d == 32) {
+    } else if (slice == 32) {
         H2GCN_LAUNCH(4, 8, true);
     } else if (vec_ok && p.d % 4 == 0) {
         H2GCN_LAUNCH(4, 64, false);
@@ -238,6 +266,8 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
                 return fail(H2GCN_ERR_INVALID_ARGUMENT, "opts->struct_size = %u", opts->struct_size);
             memcpy(&o, opts, opts->struct_size);
         }
+        if (o.slice_cols != 0 && o.slice_cols != 32 && o.slice_cols != 64 && o.slice_cols != 128 && o.slice_cols != 256)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "slice_cols = %d, supported 0 (auto), 32, 64, 128, 256", o.slice_cols);
         if (o.long_row_threshold < 0 || o.rows_per_wave < 0 || o.rows_per_wave > h2gcn::kMaxRowsPerWave)
             return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad tunable (long_row_threshold %d, rows_per_wave %d, max %d)",
                         o.long_row_threshold, o.rows_per_wave, h2gcn::kMaxRowsPerWave);
@@ -252,6 +282,7 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
         // (rows_per_wave + 1) * n_hops row pointers must fit one 64-lane load
         while ((plan->rows_per_wave + 1) * n_hops > h2gcn::kWave && plan->rows_per_wave > 1) plan->rows_per_wave--;
         plan->variant = o.variant;
+        plan->slice_cols = o.slice_cols;
         H2GCN_HIP_TRY(hipGetDevice(&plan->device));
         plan->fwd.resize(n_hops);
 
@@ -390,7 +421,9 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
         const int64_t rows_per_tile = (int64_t)p.rows_per_wave * h2gcn::kWavesPerBlock;
         p.n_tiles = (p.n_rows + rows_per_tile - 1) / rows_per_tile;
         p.tiles_per_xcd = (p.n_tiles + h2gcn::kNumXcd - 1) / h2gcn::kNumXcd;
-        return launch<false>(p, plan->variant, vec_ok, (hipStream_t)stream_v);
+        // 32-bit gather offsets when the farthest byte of X is below 4 GiB
+        const bool off32 = ((double)(plan->n_cols > 0 ? plan->n_cols - 1 : 0) * (double)ldx + d) * 4.0 < 4294967296.0;
+        return launch<false>(p, plan->variant, vec_ok, off32, plan->slice_cols, plan->n_cols, (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_f32");
     }
@@ -438,7 +471,8 @@ int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const flo
         const int64_t rows_per_tile = (int64_t)p.rows_per_wave * h2gcn::kWavesPerBlock;
         p.n_tiles = (p.n_rows + rows_per_tile - 1) / rows_per_tile;
         p.tiles_per_xcd = (p.n_tiles + h2gcn::kNumXcd - 1) / h2gcn::kNumXcd;
-        return launch<true>(p, plan->variant, vec_ok, (hipStream_t)stream_v);
+        const bool off32 = ((double)(plan->n_rows > 0 ? plan->n_rows - 1 : 0) * (double)ldg_row + (double)(s - 1) * (double)ldg_hop + d) * 4.0 < 4294967296.0;
+        return launch<true>(p, plan->variant, vec_ok, off32, plan->slice_cols, plan->n_rows, (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_T_f32");
     }

@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "h2gcn_hip.h"
 
 namespace h2gcn {
@@ -38,6 +40,10 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWave * kWavesPerBlock;
 constexpr int kNumXcd = 8;
 constexpr int kMaxRowsPerWave = 7;  // (rows_per_wave + 1) * n_hops row pointers must fit one wave-wide load
+#ifndef H2GCN_MIN_WAVES
+#define H2GCN_MIN_WAVES 6
+#endif
+constexpr int kMinWavesPerSimd = H2GCN_MIN_WAVES;  // __launch_bounds__ of the fast paths (waves per SIMD the register budget must allow)
 constexpr int kMaxTileCols = 256;   // columns one pass of a wave covers at most (64 lanes x float4)
 
 struct HopCsr {
@@ -63,6 +69,9 @@ struct LaunchParams {
     int rows_per_wave;
     int64_t n_tiles;       // row tiles of rows_per_wave * kWavesPerBlock rows
     int64_t tiles_per_xcd; // ceil(n_tiles / 8)
+    int n_slices;          // column slices of slice_cols features, processed slice-major (EXACT kernels)
+    int slice_cols;
+    int64_t blocks_per_slice;  // n_long + 8 * tiles_per_xcd
 };
 
 template <int VEC>
@@ -133,11 +142,31 @@ __device__ __forceinline__ void fma_vec(float (&acc)[VEC], float w, typename Vec
     }
 }
 
+// Gather addressing.  OFF32: every byte offset into the gather source fits 32 bits (checked on the host), so a
+// load is `global_load_dwordx4 v, v_off32, s[base]` -- scalar base + one 32-bit VGPR offset; no 64-bit
+// multiply per neighbour and 8 fewer address VGPRs per batch than full 64-bit per-lane pointers.
+template <bool OFF32>
+struct GatherAddr {
+    const char* base;                                   // wave-uniform: src + hop offset + column offset
+    typename std::conditional<OFF32, uint32_t, int64_t>::type lane_off;  // byte offset of this lane inside a row
+    typename std::conditional<OFF32, uint32_t, int64_t>::type ld_bytes;  // row stride in bytes
+    __device__ __forceinline__ const float* row(int col) const {
+        if constexpr (OFF32) {
+            return reinterpret_cast<const float*>(base + (uint32_t)(lane_off + (uint32_t)col * ld_bytes));
+        } else {
+            return reinterpret_cast<const float*>(base + (lane_off + (int64_t)col * ld_bytes));
+        }
+    }
+};
+
 // One batch of U gathers issued back to back, then U multiply-adds.  `t` is the first step of the batch
 // (wave uniform); step t+u serves neighbour (t+u)*G + g of the current 64-wide chunk.
-template <int VEC, int LPR, int U, bool MASKED>
-__device__ __forceinline__ void gather_batch(int c, float v, int t, int g, const float* __restrict__ src_lane,
-                                             int64_t ld, bool lane_active, float (&acc)[VEC]) {
+// The cross-lane reads of (c, v) always run with the full wave active (ds_bpermute returns 0 for a source
+// lane that is masked off); only the gather itself is predicated, by `take` (false on lanes whose slot is
+// padding -- they must not touch src: 0 * Inf would poison the row).
+template <int VEC, int LPR, int U, bool PREDICATED, bool OFF32>
+__device__ __forceinline__ void gather_batch(int c, float v, int t, int g, const GatherAddr<OFF32>& addr, bool take,
+                                             float (&acc)[VEC]) {
     constexpr int G = kWave / LPR;
     typename VecT<VEC>::type x[U];
     float w[U];
@@ -149,15 +178,16 @@ __device__ __forceinline__ void gather_batch(int c, float v, int t, int g, const
             cj = __builtin_amdgcn_readlane(c, t + u);
             w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t + u));
         } else {
-            const int idx = (t + u) * G + g;
+            const int idx = ((t + u) * G + g) & (kWave - 1);
             cj = lane_gather(c, idx);
             w[u] = lane_gather(v, idx);
         }
-        const float* p = src_lane + (int64_t)cj * ld;
-        if constexpr (MASKED) {
-            if (lane_active) {
+        const float* p = addr.row(cj);
+        if constexpr (PREDICATED) {
+            if (take) {
                 x[u] = load_vec<VEC>(p);
             } else {
+                w[u] = 0.f;
                 if constexpr (VEC == 1) x[u] = 0.f; else x[u] = (typename VecT<VEC>::type)(0.f);
             }
         } else {
@@ -171,12 +201,12 @@ __device__ __forceinline__ void gather_batch(int c, float v, int t, int g, const
 // Accumulate sum_j val_j * src[col_j, :] over the nonzeros [seg_begin, seg_end) of one CSR row, taking the
 // 64-wide chunks chunk0, chunk0+chunk_step, ... (regular path: all of them; long path: this wave's share).
 // Each lane group accumulates its neighbours in ascending order into acc.
-template <int VEC, int LPR, bool MASKED>
+template <int VEC, int LPR, bool MASKED, bool OFF32>
 __device__ __forceinline__ void accumulate_segment(const int32_t* __restrict__ colidx,
                                                    const float* __restrict__ vals, int64_t seg_begin,
                                                    int64_t seg_end, int chunk0, int chunk_step,
-                                                   const float* __restrict__ src_lane, int64_t ld, int lane,
-                                                   bool lane_active, float (&acc)[VEC]) {
+                                                   const GatherAddr<OFF32>& addr, int lane, bool lane_active,
+                                                   float (&acc)[VEC]) {
     constexpr int G = kWave / LPR;
     const int g = lane / LPR;
     for (int64_t base = seg_begin + (int64_t)chunk0 * kWave; base < seg_end; base += (int64_t)chunk_step * kWave) {
@@ -190,24 +220,23 @@ __device__ __forceinline__ void accumulate_segment(const int32_t* __restrict__ c
         }
         const int full = n / G;  // steps in which every lane group has a neighbour
         int t = 0;
-        for (; t + 8 <= full; t += 8) gather_batch<VEC, LPR, 8, MASKED>(c, v, t, g, src_lane, ld, lane_active, acc);
+        for (; t + 8 <= full; t += 8) gather_batch<VEC, LPR, 8, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
         if (t + 4 <= full) {
-            gather_batch<VEC, LPR, 4, MASKED>(c, v, t, g, src_lane, ld, lane_active, acc);
+            gather_batch<VEC, LPR, 4, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
             t += 4;
         }
         if (t + 2 <= full) {
-            gather_batch<VEC, LPR, 2, MASKED>(c, v, t, g, src_lane, ld, lane_active, acc);
+            gather_batch<VEC, LPR, 2, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
             t += 2;
         }
         if (t + 1 <= full) {
-            gather_batch<VEC, LPR, 1, MASKED>(c, v, t, g, src_lane, ld, lane_active, acc);
+            gather_batch<VEC, LPR, 1, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
             t += 1;
         }
         if constexpr (G > 1) {
-            // ragged last step: only the first (n - full*G) groups still have a neighbour.  Predicated, so
-            // that padding never touches src (0 * Inf would poison the row).
+            // ragged last step: only the first (n - full*G) groups still have a neighbour
             const int rem = n - full * G;
-            if (g < rem) gather_batch<VEC, LPR, 1, MASKED>(c, v, full, g, src_lane, ld, lane_active, acc);
+            if (rem > 0) gather_batch<VEC, LPR, 1, true, OFF32>(c, v, full, g, addr, lane_active && g < rem, acc);
         }
     }
 }
@@ -224,41 +253,51 @@ __device__ __forceinline__ void store_vec(float* p, const float (&acc)[VEC]) {
     }
 }
 
-// VEC   floats per lane per gathered row (4 on the fast paths)
-// LPR   lanes that cover one gathered row (EXACT: d == VEC*LPR; otherwise 64 and the columns are tiled)
-// EXACT d == VEC*LPR: one pass, no column masks
-// SUM   adjoint mode: one output row = sum over the selected hops
-template <int VEC, int LPR, bool EXACT, bool SUM>
-__global__ __launch_bounds__(kBlock) void spmm_hops_kernel(const LaunchParams p) {
-    constexpr int G = kWave / LPR;
+// VEC    floats per lane per gathered row (4 on the fast paths)
+// LPR    lanes that cover one gathered row
+// EXACT  the launch covers the feature columns in n_slices slices of exactly VEC*LPR columns, slice-major (all
+//        row tiles of slice 0, then slice 1, ...: while a slice is being processed the gather working set is
+//        n_cols * slice_cols * 4 bytes, which is what the 256 MiB Infinity Cache sees); otherwise LPR == 64
+//        and each wave loops over masked column tiles (any d)
+// SUM    adjoint mode: one output row = sum over the selected hops
+// OFF32  32-bit gather offsets (see GatherAddr)
+template <int VEC, int LPR, bool EXACT, bool SUM, bool OFF32>
+__global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hops_kernel(const LaunchParams p) {
     static_assert(EXACT || LPR == kWave, "column-tiled path uses the whole wave per row");
     __shared__ float partial[kWavesPerBlock][kMaxTileCols];
+    using off_t = typename std::conditional<OFF32, uint32_t, int64_t>::type;
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = wave_uniform(threadIdx.x >> 6);
     const int li = lane % LPR;  // lane inside its group
     const int g = lane / LPR;
     const int n_sel = p.n_sel;
-    const int tile_cols = EXACT ? VEC * LPR : ((p.d < VEC * kWave) ? p.d : VEC * kWave);
-    (void)tile_cols;
 
-    if ((int)blockIdx.x < p.n_long) {
+    // slice-major block order
+    const int64_t bid = blockIdx.x;
+    const int slice = EXACT ? (int)(bid / p.blocks_per_slice) : 0;
+    const int64_t b = EXACT ? bid - (int64_t)slice * p.blocks_per_slice : bid;
+    const int col_begin = EXACT ? slice * (VEC * LPR) : 0;
+    const int col_end = EXACT ? col_begin + VEC * LPR : p.d;
+
+    if (b < p.n_long) {
         // ---- long segment: the 4 waves of this workgroup share one (row, hop) [forward] / one row [SUM] ----
-        const int64_t entry = p.long_list[blockIdx.x];
+        const int64_t entry = p.long_list[b];
         const int64_t row = SUM ? entry : (entry >> 4);
         const int s_first = SUM ? 0 : (int)(entry & 15);
         const int s_last = SUM ? n_sel : s_first + 1;
-        for (int col0 = 0; col0 < p.d; col0 += VEC * LPR) {
+        for (int col0 = col_begin; col0 < col_end; col0 += VEC * LPR) {
             const bool lane_active = EXACT || (col0 + li * VEC < p.d);
             float acc[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
             for (int s = s_first; s < s_last; ++s) {
                 const HopCsr& h = p.hop[s];
-                const int64_t b = h.rowptr[row], e = h.rowptr[row + 1];
-                accumulate_segment<VEC, LPR, !EXACT>(h.colidx, h.vals, b, e, wave, kWavesPerBlock,
-                                                     p.src + p.src_hop_off[s] + col0 + li * VEC, p.ld_src, lane,
-                                                     lane_active, acc);
+                const int64_t sb = h.rowptr[row], se = h.rowptr[row + 1];
+                const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + col0),
+                                             (off_t)(li * VEC * 4), (off_t)(p.ld_src * 4)};
+                accumulate_segment<VEC, LPR, !EXACT, OFF32>(h.colidx, h.vals, sb, se, wave, kWavesPerBlock, addr, lane,
+                                                            lane_active, acc);
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
@@ -282,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void spmm_hops_kernel(const LaunchParams p)
     }
 
     // ---- regular path: XCD-aware tile map, each wave walks rows_per_wave consecutive rows ----
-    const int64_t tb = (int64_t)blockIdx.x - p.n_long;
+    const int64_t tb = b - p.n_long;
     const int64_t tile = (tb % kNumXcd) * p.tiles_per_xcd + tb / kNumXcd;
     if (tile >= p.n_tiles) return;
     const int rpw = p.rows_per_wave;
@@ -298,37 +337,33 @@ __global__ __launch_bounds__(kBlock) void spmm_hops_kernel(const LaunchParams p)
         if (hs < n_sel && r <= rows_here) rp = p.hop[hs].rowptr[row0 + r];
     }
     const int rp_lo = (int)(rp & 0xffffffff), rp_hi = (int)(rp >> 32);
+    auto seg_bound = [&](int l) -> int64_t {
+        return ((int64_t)__builtin_amdgcn_readlane(rp_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(rp_lo, l);
+    };
 
     for (int r = 0; r < rows_here; ++r) {
         const int64_t row = row0 + r;
-        bool skip_row = false;
         if constexpr (SUM) {
+            bool skip_row = false;  // a workgroup of the long path owns rows with any long segment
             for (int s = 0; s < n_sel; ++s) {
                 const int l0 = s * (rpw + 1) + r;
-                const int64_t b = ((int64_t)__builtin_amdgcn_readlane(rp_hi, l0) << 32) |
-                                  (uint32_t)__builtin_amdgcn_readlane(rp_lo, l0);
-                const int64_t e = ((int64_t)__builtin_amdgcn_readlane(rp_hi, l0 + 1) << 32) |
-                                  (uint32_t)__builtin_amdgcn_readlane(rp_lo, l0 + 1);
-                if (e - b >= p.long_threshold) skip_row = true;
+                if (seg_bound(l0 + 1) - seg_bound(l0) >= p.long_threshold) skip_row = true;
             }
+            if (skip_row) continue;
         }
-        if (skip_row) continue;
-        for (int col0 = 0; col0 < p.d; col0 += VEC * LPR) {
+        for (int col0 = col_begin; col0 < col_end; col0 += VEC * LPR) {
             const bool lane_active = EXACT || (col0 + li * VEC < p.d);
             float acc[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
             for (int s = 0; s < n_sel; ++s) {
                 const int l0 = s * (rpw + 1) + r;
-                const int64_t b = ((int64_t)__builtin_amdgcn_readlane(rp_hi, l0) << 32) |
-                                  (uint32_t)__builtin_amdgcn_readlane(rp_lo, l0);
-                const int64_t e = ((int64_t)__builtin_amdgcn_readlane(rp_hi, l0 + 1) << 32) |
-                                  (uint32_t)__builtin_amdgcn_readlane(rp_lo, l0 + 1);
-                if (!SUM && e - b >= p.long_threshold) continue;  // a workgroup of the long path owns it
+                const int64_t sb = seg_bound(l0), se = seg_bound(l0 + 1);
+                if (!SUM && se - sb >= p.long_threshold) continue;  // a workgroup of the long path owns it
                 const HopCsr& h = p.hop[s];
-                accumulate_segment<VEC, LPR, !EXACT>(h.colidx, h.vals, b, e, 0, 1,
-                                                     p.src + p.src_hop_off[s] + col0 + li * VEC, p.ld_src, lane,
-                                                     lane_active, acc);
+                const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + col0),
+                                             (off_t)(li * VEC * 4), (off_t)(p.ld_src * 4)};
+                accumulate_segment<VEC, LPR, !EXACT, OFF32>(h.colidx, h.vals, sb, se, 0, 1, addr, lane, lane_active, acc);
                 if constexpr (!SUM) {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);

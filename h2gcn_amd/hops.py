@@ -30,14 +30,14 @@ class HopPlan:
     rowptr, colidx, vals : sequences of H CUDA tensors (int64 ``[n_rows+1]``, int32 ``[nnz]``, float32 ``[nnz]``)
     n_cols : number of columns (rows of the dense operand ``X``)
     build_transpose : also build ``A_k^T`` on the device (needed for ``backward``)
-    long_row_threshold, rows_per_wave, variant : schedule tunables (0 = library default)
+    long_row_threshold, rows_per_wave, variant, slice_cols : schedule tunables (0 = library default)
     validate : run the one-time column-range check (TensorFlow validates indices per call; this once)
     """
 
     def __init__(self, rowptr: Sequence[torch.Tensor], colidx: Sequence[torch.Tensor],
                  vals: Sequence[torch.Tensor], n_cols: int, *, build_transpose: bool = False,
                  long_row_threshold: int = 0, rows_per_wave: int = 0, variant: int = 0,
-                 validate: bool = True):
+                 slice_cols: int = 0, validate: bool = True):
         H = len(rowptr)
         _require(1 <= H <= _capi.MAX_HOPS, f"need 1..{_capi.MAX_HOPS} hop matrices, got {H}")
         _require(len(colidx) == H and len(vals) == H, "rowptr/colidx/vals lists differ in length")
@@ -75,6 +75,7 @@ class HopPlan:
         opts.long_row_threshold = int(long_row_threshold)
         opts.rows_per_wave = int(rows_per_wave)
         opts.variant = int(variant)
+        opts.slice_cols = int(slice_cols)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             st = L.h2gcn_plan_create(H, self.n_rows, self.n_cols, rp_a, ci_a, va_a, C.byref(opts),

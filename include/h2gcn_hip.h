@@ -63,7 +63,9 @@ typedef struct h2gcn_plan_opts {
                                     waves of one workgroup (LDS-staged partial sums); default 1024         */
     int32_t rows_per_wave;       /* consecutive rows a wave walks in the regular path; default 4           */
     int32_t variant;             /* kernel variant selector, 0 = default                   */
-    int32_t reserved[3];
+    int32_t slice_cols;          /* feature columns per slice of the slice-major schedule: 32/64/128/256,
+                                    0 = heuristic (narrower slices when X is far beyond the Infinity Cache)  */
+    int32_t reserved[2];
 } h2gcn_plan_opts;
 
 /* Opaque: row-bin tables (long-segment list), optional transposed CSR, launch geometry. */

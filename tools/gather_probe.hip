@@ -1,0 +1,62 @@
+// gather_probe.hip -- micro-benchmark (not part of the product): bandwidth of random ROW gathers on MI355X as a
+// function of table size (L2 / Infinity Cache / HBM resident) and row width.  It bounds what the SpMM's gather
+// stream can reach: each wave reads `rows_per_wave` pseudo-random rows of `row_bytes` (16 B per lane, LPR lanes
+// per row, G = 64/LPR rows per load instruction, 8 loads in flight), sums them, writes one row.
+//   hipcc --offload-arch=gfx950 -O3 -o gather_probe tools/gather_probe.hip && ./gather_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__device__ inline unsigned long long mix(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ table, long n_rows, int gathers_per_wave, float4* out) {
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, li = lane % LPR;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int t = 0; t < gathers_per_wave; t += 8 * G) {
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long r = mix((unsigned long long)wave * 1000003ull + t + u * G + g) % (unsigned long long)n_rows;
+            x[u] = table[r * LPR + li];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+    }
+    if (g == 0) __builtin_nontemporal_store(acc.x + acc.y + acc.z + acc.w, (float*)out + wave * LPR + li);
+}
+
+template <int LPR>
+double run(const float4* table, long n_rows, long n_waves, int gpw, float4* out) {
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(gather_kernel<LPR>, dim3(n_waves / 4), dim3(256), 0, 0, table, n_rows, gpw, out);
+    CHECK(hipEventRecord(a));
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gather_kernel<LPR>, dim3(n_waves / 4), dim3(256), 0, 0, table, n_rows, gpw, out);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    return (double)n_waves * gpw * LPR * 16.0 * reps / (ms * 1e-3) / 1e9;
+}
+
+int main() {
+    const size_t max_bytes = 8ull << 30;
+    float4* table; CHECK(hipMalloc(&table, max_bytes)); CHECK(hipMemset(table, 0, max_bytes));
+    const long n_waves = 1 << 18; const int gpw = 512;
+    float4* out; CHECK(hipMalloc(&out, n_waves * 64 * sizeof(float4)));
+    printf("%12s %10s %12s\n", "table_MiB", "row_bytes", "gather_GB/s");
+    const size_t sizes[] = {16ull << 20, 128ull << 20, 512ull << 20, 1229ull << 20, 4096ull << 20, 8192ull << 20};
+    for (size_t sz : sizes) {
+        printf("%12zu %10d %12.0f\n", sz >> 20, 128, run<8>(table, sz / 128, n_waves, gpw, out));
+        printf("%12zu %10d %12.0f\n", sz >> 20, 256, run<16>(table, sz / 256, n_waves, gpw, out));
+        printf("%12zu %10d %12.0f\n", sz >> 20, 512, run<32>(table, sz / 512, n_waves, gpw, out));
+        printf("%12zu %10d %12.0f\n", sz >> 20, 1024, run<64>(table, sz / 1024, n_waves, gpw, out));
+    }
+    return 0;
+}
