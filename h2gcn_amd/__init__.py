@@ -19,4 +19,4 @@ __version__ = "0.1.0"
 
 from . import _capi  # noqa: F401  (does not load the library until first use)
 from .hops import HopPlan  # noqa: F401
-from .layers import GCNLayer, hop_spmm  # noqa: F401
+from .layers import ConcatLayer, GCNLayer, SliceLayer, SparseDense, hop_spmm  # noqa: F401

@@ -1,0 +1,179 @@
+"""Planetoid-format data (the on-disk format feeding the path) and the tensors the model consumes.
+
+On-disk format (reference ``PlanetoidData.load_data``, ``h2gcn/datasets/_dataset.py:195-305``): seven pickles
+``<name>.{x,y,tx,ty,allx,ally,graph}`` (scipy CSR features / one-hot label arrays / dict-of-neighbour-lists) plus
+``<name>.test.index`` (one node id per line).  ``allx`` rows come first, then the test rows ``tx`` in the order of
+``test.index``; ids missing from the contiguous test range are isolated nodes (citeseer) and become all-zero,
+label-less rows that every mask excludes.  Splits: train = the first ``len(y)`` nodes, test = ``test.index``,
+validation = the next ``val_size`` nodes after the training block (or everything left if fewer).
+
+``get_tensors`` plays the role of ``getTensors`` (``:537-584``): features become a device-resident sparse operand
+(a 1-hop :class:`~h2gcn_amd.hops.HopPlan`, so the ``SparseDense`` embedding runs on the same HIP kernel), the
+normalised hop matrices become the ``adj_hops`` :class:`HopPlan`, labels/masks become dense tensors.
+"""
+from __future__ import annotations
+
+import pickle
+import warnings
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+
+from .. import operands
+
+
+def _load_pickle(path):
+    with open(path, "rb") as f:
+        return pickle.load(f, encoding="latin1")
+
+
+def adjacency_from_neighbour_lists(graph: dict) -> sp.csr_matrix:
+    """Symmetric binary float32 adjacency over nodes ``0..len(graph)-1`` (a listed self-loop gives a 1 on the
+    diagonal), as ``nx.adjacency_matrix(nx.from_dict_of_lists(graph), nodelist=range(len(graph)))`` yields."""
+    n = len(graph)
+    src = np.fromiter((u for u, nbrs in graph.items() for _ in nbrs), dtype=np.int64)
+    dst = np.fromiter((v for nbrs in graph.values() for v in nbrs), dtype=np.int64)
+    rows = np.concatenate([src, dst])
+    cols = np.concatenate([dst, src])
+    a = sp.csr_matrix((np.ones(len(rows), dtype=np.float32), (rows, cols)), shape=(n, n))
+    a.data[:] = 1.0  # duplicates were summed by the constructor
+    a.sort_indices()
+    return a
+
+
+class PlanetoidData:
+    def __init__(self, dataset_str: str, dataset_path, val_size: Optional[int] = None):
+        self.dataset_str = dataset_str
+        self.dataset_path = str(dataset_path)
+        self.val_size = val_size
+        self.preprocessed_feature = False
+        self._load()
+
+    # ------------------------------------------------------------------ loading
+    def _load(self):
+        base = Path(self.dataset_path)
+        x, y, tx, ty, allx, ally, graph = (_load_pickle(base / f"{self.dataset_str}.{n}")
+                                           for n in ("x", "y", "tx", "ty", "allx", "ally", "graph"))
+        test_order = [int(line.strip()) for line in open(base / f"{self.dataset_str}.test.index")]
+        test_sorted = np.sort(test_order)
+        lo, hi = int(test_sorted[0]), int(test_sorted[-1])
+        non_valid = set()
+        if hi - lo + 1 != len(test_sorted):
+            # isolated nodes inside the test range: give them zero feature / label rows
+            print(f"Patch for citeseer dataset is applied for dataset {self.dataset_str} at {self.dataset_path}")
+            tx_full = sp.lil_matrix((hi - lo + 1, x.shape[1]))
+            tx_full[test_sorted - lo, :] = tx
+            ty_full = np.zeros((hi - lo + 1, y.shape[1]))
+            ty_full[test_sorted - lo, :] = ty
+            tx, ty = tx_full, ty_full
+            non_valid = set(range(lo, hi + 1)) - set(test_sorted.tolist())
+        features = sp.vstack((allx, tx)).tolil()
+        features[test_order, :] = features[test_sorted, :]
+        labels = np.vstack((ally, ty))
+        labels[test_order, :] = labels[test_sorted, :]
+        non_valid |= set(np.where(labels.sum(1) == 0)[0].tolist())
+
+        n = labels.shape[0]
+        train_mask = np.zeros(n, dtype=bool)
+        train_mask[: len(y)] = True
+        test_mask = np.zeros(n, dtype=bool)
+        test_mask[test_sorted] = True
+        val_mask = ~(train_mask | test_mask)
+        if self.val_size is not None:
+            if val_mask.sum() > self.val_size:
+                val_mask = np.zeros(n, dtype=bool)
+                val_mask[len(y): len(y) + self.val_size] = True
+            else:
+                print(f"Val set size set to {val_mask.sum()} due to insufficient samples.")
+        for i in non_valid:
+            for name, m in (("training", train_mask), ("test", test_mask), ("val", val_mask)):
+                if m[i]:
+                    warnings.warn(f"Non valid samples detected in {name} set")
+                    m[i] = False
+                    break
+        self.non_valid_samples = non_valid
+        self.sparse_adj = adjacency_from_neighbour_lists(graph)
+        self.features = sp.csr_matrix(features)
+        self.y_all = labels
+        self.train_mask, self.val_mask, self.test_mask = train_mask, val_mask, test_mask
+        self.y_train, self.y_val, self.y_test = (np.where(m[:, None], labels, 0.0) for m in (train_mask, val_mask, test_mask))
+
+    # ------------------------------------------------------------------ properties the model plugin uses
+    @property
+    def num_samples(self) -> int:
+        return self.y_all.shape[0]
+
+    @property
+    def num_labels(self) -> int:
+        return self.y_all.shape[1]
+
+    @property
+    def labels(self) -> np.ndarray:
+        return np.argmax(self.y_all, axis=1)
+
+    def row_normalize_features(self):
+        self.features = operands.row_normalize_features(self.features)
+        self.preprocessed_feature = True
+
+    def adj_remove_eye(self):
+        self.sparse_adj = operands.remove_self_loops(self.sparse_adj)
+
+    def set_identity_features(self):
+        self.features = sp.identity(self.num_samples, dtype=np.float32, format="csr")
+
+    # ------------------------------------------------------------------ tensors
+    def get_tensors(self, device, adj_norm_hops: Optional[Sequence[str]] = None, norm: str = operands.SYM_NORMALIZED,
+                    build_transpose: bool = True) -> dict:
+        """``adj`` / ``features`` / ``adj_hops`` as device operands + dense label/mask tensors (keys as the
+        reference's ``tensors`` namespace: ``H2GCN.py:66,77-79``)."""
+        import torch
+
+        from ..hops import HopPlan
+
+        t = {}
+        t["features"] = HopPlan.from_scipy([self.features], device, build_transpose=build_transpose)
+        t["adj"] = HopPlan.from_scipy([self.sparse_adj], device)
+        if adj_norm_hops:
+            hops = operands.build_adj_norm_hops(self.sparse_adj, adj_norm_hops, norm)
+            t["adj_hops"] = HopPlan.from_scipy(hops, device, build_transpose=build_transpose)
+        else:
+            t["adj_hops"] = None
+        for name in ("y_all", "y_train", "y_val", "y_test"):
+            t[name] = torch.from_numpy(np.asarray(getattr(self, name), dtype=np.float32)).to(device)
+        for name in ("train_mask", "val_mask", "test_mask"):
+            t[name] = torch.from_numpy(getattr(self, name)).to(device)
+        t["labels"] = torch.from_numpy(self.labels).to(device)
+        return t
+
+
+def export_planetoid(path, name, adj, features, labels_onehot, n_train: int, test_ids: Sequence[int],
+                     n_allx: Optional[int] = None):
+    """Write a graph in the planetoid on-disk format (inverse of the loader; used to round-trip fixtures and to
+    hand synthetic graphs to the entry point).  ``test_ids`` are the test nodes, in the order they should appear
+    in ``test.index``; nodes inside their contiguous range that are not listed become "isolated" (citeseer case)."""
+    path = Path(path)
+    path.mkdir(parents=True, exist_ok=True)
+    adj = sp.csr_matrix(adj)
+    features = sp.csr_matrix(features)
+    labels_onehot = np.asarray(labels_onehot)
+    test_sorted = np.sort(np.asarray(test_ids))
+    n_allx = int(test_sorted[0]) if n_allx is None else n_allx
+    # after loading, row test_ids[k] holds the k-th row of tx  ->  tx row k = features[test_ids[k]] ... but the loader
+    # first places tx rows at the SORTED positions and then permutes: features[test_order] = features[test_sorted]
+    # so tx (in file order) must be the rows of the sorted ids permuted accordingly: tx[j] = final[test_order[j]]
+    # where j indexes sorted position.
+    order = np.asarray(test_ids)
+    tx = features[order, :]
+    ty = labels_onehot[order, :]
+    objs = {
+        "x": features[:n_train, :], "y": labels_onehot[:n_train, :],
+        "allx": features[:n_allx, :], "ally": labels_onehot[:n_allx, :],
+        "tx": tx, "ty": ty,
+        "graph": {int(i): [int(j) for j in adj.indices[adj.indptr[i]:adj.indptr[i + 1]]] for i in range(adj.shape[0])},
+    }
+    for k, v in objs.items():
+        with open(path / f"{name}.{k}", "wb") as f:
+            pickle.dump(v, f)
+    (path / f"{name}.test.index").write_text("".join(f"{int(i)}\n" for i in test_ids))

@@ -66,3 +66,59 @@ class GCNLayer(torch.nn.Module):
 
     def extra_repr(self) -> str:
         return f"hops={None if self.hops is None else sorted(self.hops)}"
+
+
+class SparseDense(torch.nn.Module):
+    """Sparse features x dense kernel (reference ``SparseDense``, ``h2gcn/models/_layers.py:22-52``): the feature
+    embedding ``X_sp[N, F] @ W[F, units]`` (+ bias, + activation).  The sparse operand is a 1-hop
+    :class:`HopPlan` holding the feature matrix in CSR, so the product runs on the same HIP kernel as the hop
+    aggregation; the kernel gradient ``X_sp^T @ dY`` is the plan's adjoint launch."""
+
+    def __init__(self, input_dim: int, output_dim: int, use_bias: bool = False, activation=None):
+        super().__init__()
+        self.kernel = torch.nn.Parameter(torch.empty(input_dim, output_dim))
+        torch.nn.init.xavier_uniform_(self.kernel)  # keras default: glorot_uniform
+        self.bias = torch.nn.Parameter(torch.zeros(output_dim)) if use_bias else None
+        self.activation = activation
+
+    def forward(self, inputs: HopPlan) -> torch.Tensor:
+        if not isinstance(inputs, HopPlan) or inputs.n_hops != 1:
+            raise TypeError("SparseDense expects the sparse feature operand as a 1-hop HopPlan")
+        if inputs.n_cols != self.kernel.shape[0]:
+            raise ValueError(f"features have {inputs.n_cols} columns, kernel has {self.kernel.shape[0]} rows")
+        out = hop_spmm(inputs, self.kernel)[:, 0, :]
+        if self.bias is not None:
+            out = out + self.bias
+        if self.activation is not None:
+            out = self.activation(out)
+        return out
+
+
+class ConcatLayer(torch.nn.Module):
+    """``concat([inputs] + [tagged[name] for name in tags])`` on the last axis (reference ``ConcatLayer``,
+    ``_layers.py:83-96``).  Tagged outputs are taken in the order they were produced (the reference iterates the
+    kwargs dict, i.e. insertion order), not in the order the tags are listed."""
+
+    def __init__(self, tags, axis: int = -1, addInputs: bool = True):
+        super().__init__()
+        self.tags = list(tags)
+        self.axis = axis
+        self.addInputs = addInputs
+
+    def forward(self, *args, **tagged) -> torch.Tensor:
+        selected = [v for name, v in tagged.items() if name in self.tags]
+        return torch.cat((list(args) if self.addInputs else []) + selected, dim=self.axis)
+
+
+class SliceLayer(torch.nn.Module):
+    """Column slice of the input or of a tagged output (reference ``SliceLayer``, ``_layers.py:107-116``)."""
+
+    def __init__(self, loadTag, sliceObj, **_):
+        super().__init__()
+        self.tag = loadTag
+        self.sliceObj = sliceObj
+
+    def forward(self, inputs, **tagged):
+        if self.tag:
+            inputs = tagged[self.tag]
+        return inputs[:, self.sliceObj]

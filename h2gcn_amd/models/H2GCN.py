@@ -1,0 +1,286 @@
+"""``H2GCN`` model plugin: the caller of the hot path, re-expressed in torch on top of ``GCNLayer``.
+
+Mirror of ``h2gcn/models/H2GCN.py``: CLI flags (``:9-30``), the argparse hook that preprocesses the data and builds
+the model (``:33-54``), step closures (``:66-127``), best-validation bookkeeping (``:136-195``) and the generic
+layer interpreter driven by the parsed ``--network_setup`` (``:209-346``), with the masked cross-entropy + L2 loss
+(``:363-367``).  Differences by design: tensors live on one MI355X; ``adj_hops`` and the sparse features are
+``HopPlan`` device operands; every ``G`` layer is ONE fused 1+2-hop HIP launch writing ``[N, H, d]`` (so the
+following ``V`` flatten is a view, not a copy); only the best model state is kept (in memory) instead of a TF
+checkpoint per epoch; signac bookkeeping and the attention / experimental layer kinds are not carried over.
+"""
+from __future__ import annotations
+
+import operator
+
+import torch
+
+from .. import layers as L
+from ..modules import controller, logger
+from . import Layer, parse_network_setup
+from ._metrics import masked_accuracy, masked_softmax_cross_entropy
+
+
+def add_subparser_args(parser):
+    g = parser.add_argument_group("H2GCN Model Arguments (H2GCN.py)")
+    g.add_argument("--network_setup", type=str, default="M64-R-T1-G-V-T2-G-V-C1-C2-D0.5-MO",
+                   help="Default to H2GCN-2 (%(default)s)")
+    g.add_argument("--dropout", type=float, default=0.5, help="Default dropout rate")
+    g.add_argument("--hidden", type=int, default=64)
+    g.add_argument("--adj_nhood", default=["1", "2"], type=str, nargs="+")
+    g.add_argument("--optimizer", type=str, default="adam", help="(default: %(default)s)")
+    g.add_argument("--lr", type=float, default=0.01, help="(default: %(default)s)")
+    g.add_argument("--l2_regularize_weight", type=float, default=5e-4, help="(default: %(default)s)")
+    g.add_argument("--early_stopping", type=int, default=0,
+                   help="Number of epochs used to decide early stopping (0 to disable) (default: %(default)s)")
+    g.add_argument("--best_val_criteria", choices=["val_acc", "val_loss"], default="val_acc")
+    g.add_argument("--no_feature_normalize", action="store_true")
+    g.add_argument("--adj_norm", choices=["sym", "rw"], default="sym",
+                   help="hop normalisation: sym = D^-1/2 A D^-1/2 (reference default), rw = D^-1 A")
+    g.add_argument("--device", type=str, default="cuda:0", dest="_device")
+    parser.function_hooks["argparse"].append(argparse_callback)
+
+
+def argparse_callback(args):
+    dataset = args.objects["dataset"]
+    layer_setups = parse_network_setup(args.network_setup, dataset.num_labels, _dense_units=args.hidden,
+                                       _dropout_rate=args.dropout, parse_preprocessing=True)
+    uses_hops = any(kind == Layer.GCN for kind, _ in layer_setups)
+    preprocessing_data(args, adj_norm_hops=args.adj_nhood if uses_hops else None)
+    initialize_model(args, layer_setups, args.optimizer, args.lr, args.l2_regularize_weight, args.early_stopping)
+
+
+def preprocessing_data(args, adj_norm_hops=None):
+    """feature row-normalisation (unless disabled) -> drop self loops -> device operands
+    (reference ``preprocessing_data``, ``:46-54``)."""
+    dataset = args.objects["dataset"]
+    if not torch.cuda.is_available():
+        raise RuntimeError("h2gcn_amd runs the propagation on an MI355X; no GPU is visible and there is no CPU fallback")
+    if not args.no_feature_normalize:
+        dataset.row_normalize_features()
+    dataset.adj_remove_eye()
+    args.objects["tensors"] = dataset.get_tensors(torch.device(args._device), adj_norm_hops=adj_norm_hops,
+                                                  norm=args.adj_norm)
+
+
+def make_optimizer(name: str, params, lr: float):
+    name = name.lower()
+    if name == "adam":  # keras defaults: beta 0.9 / 0.999, epsilon 1e-7
+        return torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=1e-7)
+    if name == "sgd":
+        return torch.optim.SGD(params, lr=lr)
+    if name == "rmsprop":
+        return torch.optim.RMSprop(params, lr=lr, alpha=0.9, eps=1e-7)
+    raise ValueError(f"unsupported optimizer {name!r}")
+
+
+def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, early_stopping):
+    tensors = args.objects["tensors"]
+    device = torch.device(args._device)
+    model = H2GCN(layer_setups, input_dim=tensors["features"].n_cols, n_hops=(tensors["adj_hops"].n_hops
+                  if tensors["adj_hops"] is not None else 0), l2_regularize_weight=l2_regularize_weight).to(device)
+    optimizer = make_optimizer(optimizer, model.parameters(), lr)
+    snapshot = logger.BestSnapshot()
+
+    def train_step(adj, adj_hops, features, y_train, train_mask, **kwargs):
+        model.train()
+        optimizer.zero_grad(set_to_none=True)
+        predictions = model(adj, features, adj_hops)
+        train_loss = model.loss(predictions, y_train, train_mask)
+        train_loss.backward()
+        optimizer.step()
+        return dict(train_loss=train_loss.detach())
+
+    @torch.no_grad()
+    def test_step(adj, adj_hops, features, y_train, train_mask, y_val, val_mask, y_test, test_mask, **kwargs):
+        model.eval()
+        predictions = model(adj, features, adj_hops)
+        return dict(
+            train_acc=masked_accuracy(predictions, y_train, train_mask),
+            val_acc=masked_accuracy(predictions, y_val, val_mask),
+            test_accuracy=masked_accuracy(predictions, y_test, test_mask),
+            val_loss=model.loss(predictions, y_val, val_mask),                       # includes the L2 term (:100)
+            test_loss=masked_softmax_cross_entropy(predictions, y_test, test_mask),  # does not (:101-102)
+            monitor=dict(),
+        )
+
+    @torch.no_grad()
+    def predict_step(adj, adj_hops, features, **kwargs):
+        model.eval()
+        return model(adj, features, adj_hops)
+
+    @torch.no_grad()
+    def embed_step(adj, adj_hops, features, **kwargs):
+        model.eval()
+        return model.get_embeddings(adj, features, adj_hops)
+
+    stats_printer = logger.EpochStatsPrinter()
+    args.objects["statsPrinter"] = stats_printer
+    args.objects["best_val_stats"] = None
+    args.objects["early_stopping"] = controller.SlidingMeanEarlyStopping(early_stopping)
+
+    def post_epoch_callback(epoch, args):
+        stats = {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in args.objects["epoch_stats"].items()}
+        args.objects["epoch_stats"] = stats
+        stats_printer(epoch, stats)
+        if args.objects["early_stopping"](stats["val_loss"]):
+            print("Early stopping...")
+            args.epochs = epoch
+        better = operator.ge if args.best_val_criteria == "val_acc" else operator.le
+        best = args.objects["best_val_stats"]
+        if best is None or better(stats[args.best_val_criteria], best[args.best_val_criteria]):
+            args.objects["best_val_stats"] = dict(stats, epoch=epoch)
+            snapshot.save(model, optimizer)
+
+    def post_train_callback(args):
+        print("Restoring the best performance model")
+        snapshot.restore(model, optimizer)
+        stats = args.objects["test_step"](**args.objects["tensors"])
+        args.objects["best_val_stats"]["monitor"] = stats["monitor"]
+        print("Best performance:")
+        stats_printer.from_dict(args.objects["best_val_stats"])
+        snapshot.write(getattr(args, "checkpoint_dir", None))
+
+    args.objects.update(model=model, optimizer=optimizer, checkpoint=snapshot, train_step=train_step,
+                        test_step=test_step, predict_step=predict_step, embed_step=embed_step)
+    args.objects["post_epoch_callbacks"].append(post_epoch_callback)
+    args.objects["post_train_callbacks"].append(post_train_callback)
+
+
+class Dense(torch.nn.Module):
+    """keras ``Dense``: ``x @ kernel (+ bias)``, glorot-uniform kernel ``[in, out]``."""
+
+    def __init__(self, input_dim: int, units: int, use_bias: bool):
+        super().__init__()
+        self.kernel = torch.nn.Parameter(torch.empty(input_dim, units))
+        torch.nn.init.xavier_uniform_(self.kernel)
+        self.bias = torch.nn.Parameter(torch.zeros(units)) if use_bias else None
+
+    def forward(self, x):
+        y = x @ self.kernel
+        return y if self.bias is None else y + self.bias
+
+
+class _SparseToDense(torch.nn.Module):
+    """``I`` token: the sparse feature operand as a dense matrix (reference ``tf.sparse.to_dense``, ``:263-265``)."""
+
+    def forward(self, plan):
+        csr = torch.sparse_csr_tensor(plan.rowptr[0], plan.colidx[0].to(torch.int64), plan.vals[0],
+                                      size=(plan.n_rows, plan.n_cols))
+        return csr.to_dense()
+
+
+class H2GCN(torch.nn.Module):
+    """Generic interpreter of a parsed network setup (reference ``H2GCN(keras.Model)``, ``:209-346``).
+
+    Dispatch kinds (``:314-325``): concat/slice layers receive the tag store, ``G`` layers receive
+    ``(adjhops, inputs)``, everything else ``(inputs)``; an output tagged ``T<name>`` is stored for later
+    concats (``:339-341``).  Feature widths are tracked statically (keras builds lazily)."""
+
+    def __init__(self, layer_setups, input_dim: int, n_hops: int = 2, sparse_input: bool = True,
+                 l2_regularize_weight: float = 0.0):
+        super().__init__()
+        self.l2 = float(l2_regularize_weight)
+        self.layer_objs = torch.nn.ModuleList()
+        self.kinds = []
+        self.tags = {}
+        self.graph_hops_inds, self.concat_inds = set(), set()
+        self.embedding_ind = self.output_ind = None
+        self.regularized = []
+        width = int(input_dim)       # width of the running activation (per node)
+        tag_width = {}
+        pending_hops = None          # set after a G layer until the next V: activation is [N, H, width]
+        for kind, conf in layer_setups:
+            conf = dict(conf)
+            tag = conf.pop("tag", None)
+            ind = len(self.layer_objs)
+            if kind == Layer.DENSE:
+                if conf.get("isEmbedding"):
+                    self.embedding_ind = ind
+                if conf.get("beginOutput"):
+                    self.output_ind = ind
+                if sparse_input:
+                    layer = L.SparseDense(width, conf["units"], use_bias=conf["use_bias"])
+                    sparse_input = False
+                else:
+                    layer = Dense(width, conf["units"], conf["use_bias"])
+                self.regularized.append(layer)
+                width = conf["units"]
+            elif kind == Layer.DROPOUT:
+                if sparse_input:
+                    raise NotImplementedError("dropout on the sparse input (SparseDropout) is not supported")
+                layer = torch.nn.Dropout(conf["dropout_rate"])
+            elif kind == Layer.SLICE:
+                self.concat_inds.add(ind)
+                layer = L.SliceLayer(**conf)
+                src = tag_width[conf["loadTag"]] if conf["loadTag"] else width
+                width = len(range(*conf["sliceObj"].indices(src)))
+            elif kind == Layer.IDENTITY:
+                layer = _SparseToDense()
+                sparse_input = False
+            elif kind == Layer.GCN:
+                if sparse_input:
+                    raise ValueError("a G layer needs dense inputs (put M/F or I before it)")
+                self.graph_hops_inds.add(ind)
+                layer = L.GCNLayer(**conf)
+                sel = n_hops if conf["hops"] is None else len([h for h in range(n_hops) if h in conf["hops"]])
+                pending_hops = sel
+            elif kind == Layer.RELU:
+                layer = torch.nn.ReLU()
+            elif kind == Layer.VECTORIZE:
+                layer = torch.nn.Flatten(start_dim=1)
+                if pending_hops is not None:
+                    width *= pending_hops
+                    pending_hops = None
+            elif kind == Layer.CONCAT:
+                self.concat_inds.add(ind)
+                layer = L.ConcatLayer(tags=conf["tags"], addInputs=conf["addInputs"])
+                width = (width if conf["addInputs"] else 0) + sum(tag_width[t] for t in conf["tags"] if t in tag_width)
+            else:
+                raise ValueError(f"Unsupported layer type {kind} specified in this model.")
+            if conf.get("isEmbedding") and kind != Layer.DENSE:
+                self.embedding_ind = ind
+            self.layer_objs.append(layer)
+            self.kinds.append(kind)
+            if tag:
+                self.tags[ind] = tag
+                tag_width[tag] = width
+        self.output_width = width
+
+    def forward(self, adj, inputs, adjhops, return_before: int = 0, execute_after: int = 0, tagged_out: dict = None):
+        n_layers = len(self.layer_objs)
+        if return_before <= 0:
+            return_before = n_layers + return_before
+        if execute_after < 0:
+            execute_after = n_layers + execute_after
+        tagged = {}
+        for ind, layer in enumerate(self.layer_objs):
+            if ind == return_before:
+                return inputs
+            if ind < execute_after:
+                continue
+            if ind in self.concat_inds:
+                inputs = layer(inputs, **tagged)
+            elif ind in self.graph_hops_inds:
+                inputs = layer(adjhops, inputs)
+            else:
+                inputs = layer(inputs)
+            if ind in self.tags:
+                tagged[self.tags[ind]] = inputs
+        if tagged_out is not None:
+            tagged_out.update(tagged)
+        return inputs
+
+    def get_embeddings(self, adj, inputs, adjhops):
+        if self.embedding_ind is None:
+            raise ValueError("no layer is marked as the embedding (E)")
+        return self(adj, inputs, adjhops, return_before=self.embedding_ind + 1)
+
+    def regularization_loss(self) -> torch.Tensor:
+        """keras ``regularizers.l2(w)`` on every dense kernel: ``w * sum(kernel ** 2)`` (``:239-240,247-248``)."""
+        total = torch.zeros((), device=self.regularized[0].kernel.device) if self.regularized else torch.zeros(())
+        for layer in self.regularized:
+            total = total + self.l2 * (layer.kernel ** 2).sum()
+        return total
+
+    def loss(self, predictions, labels, mask) -> torch.Tensor:
+        return masked_softmax_cross_entropy(predictions, labels, mask) + self.regularization_loss()

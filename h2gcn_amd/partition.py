@@ -108,18 +108,20 @@ class PipelinedHopAggregation:
         self.device = device
         if plan.n_cols != self.n or plan.n_rows != self.r1 - self.r0:
             raise ValueError(f"plan is {plan.n_rows} x {plan.n_cols}, expected {self.r1 - self.r0} x {self.n}")
+        self.use_streams = torch.device(device).type == "cuda"  # CPU/gloo (tests): same schedule, no streams
         if self.world > 1:
-            self.comm_stream = torch.cuda.Stream(device=device)
+            self.comm_stream = torch.cuda.Stream(device=device) if self.use_streams else None
             self.send = [torch.zeros((self.per, self.dc), dtype=torch.float32, device=device) for _ in range(self.C)]
             self.full = [torch.empty((self.world * self.per, self.dc), dtype=torch.float32, device=device)
                          for _ in range(self.C)]
-            self.staged = torch.cuda.Event()
-            self.ready = [torch.cuda.Event() for _ in range(self.C)]
+            if self.use_streams:
+                self.staged = torch.cuda.Event()
+                self.ready = [torch.cuda.Event() for _ in range(self.C)]
         #: set to a list to have (start, end) timing-event pairs appended around every SpMM launch
         self.kernel_events = None
 
     def _spmm(self, x, out):
-        if self.kernel_events is None:
+        if self.kernel_events is None or not self.use_streams:
             self.plan.spmm(x, out=out)
             return
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -140,9 +142,14 @@ class PipelinedHopAggregation:
             for c in range(self.C):  # chunked on one GPU: same schedule without the exchange
                 self._spmm(x_local[:, c * dc:(c + 1) * dc], out[:, :, c * dc:(c + 1) * dc])
             return out
-        main = torch.cuda.current_stream(self.device)
         for c in range(self.C):
             self.send[c][:n_local].copy_(x_local[:, c * dc:(c + 1) * dc])
+        if not self.use_streams:
+            for c in range(self.C):
+                dist.all_gather_into_tensor(self.full[c], self.send[c], group=self.group)
+                self._spmm(self.full[c][: self.n], out[:, :, c * dc:(c + 1) * dc])
+            return out
+        main = torch.cuda.current_stream(self.device)
         self.staged.record(main)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self.staged)

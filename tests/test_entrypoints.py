@@ -1,0 +1,119 @@
+"""CPU suite: the host plumbing either side of the path -- planetoid on-disk format, plugin/argparse contract,
+metrics, early stopping, static width tracking of the model interpreter.  No GPU compute."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import load_planetoid_golden
+from h2gcn_amd.datasets._dataset import PlanetoidData, adjacency_from_neighbour_lists, export_planetoid
+from h2gcn_amd.models import parse_network_setup
+from h2gcn_amd.models._metrics import masked_accuracy, masked_softmax_cross_entropy
+from h2gcn_amd.modules import arguments
+from h2gcn_amd.modules.controller import SlidingMeanEarlyStopping
+from oracle import h2gcn_model as om
+
+
+def _export_fixture(g, tmp_path, name):
+    """Write the golden (reference-loaded) graph back to planetoid files; isolated citeseer nodes (all-zero
+    label rows inside the test range) are left out of test.index, as in the original files."""
+    n = g["n"]
+    n_train = int(g["train_mask"].sum())
+    y = g["y_all"].astype(np.float64)
+    test_ids = np.where(g["test_mask"])[0]
+    rng = np.random.default_rng(0)
+    test_ids = rng.permutation(test_ids)  # test.index is not sorted in the real files either
+    lo = int(g["test_mask"].nonzero()[0].min())
+    isolated = [i for i in range(lo, n) if y[i].sum() == 0]
+    if isolated:
+        lo = min(lo, min(isolated))
+    export_planetoid(tmp_path, name, g["adj_raw"], g["feat_raw"], y, n_train, test_ids.tolist(), n_allx=lo)
+    return n_train
+
+
+@pytest.mark.parametrize("name", ["cora", "citeseer"])
+def test_planetoid_round_trip_matches_reference_loader(name, tmp_path):
+    g = load_planetoid_golden(name)  # produced by the reference's PlanetoidData
+    _export_fixture(g, tmp_path, f"ind.{name}")
+    d = PlanetoidData(f"ind.{name}", tmp_path, val_size=500)
+    a = sp.csr_matrix(d.sparse_adj); a.sort_indices()
+    assert (abs(a - g["adj_raw"])).nnz == 0
+    assert abs(sp.csr_matrix(d.features) - g["feat_raw"]).max() == 0
+    assert np.array_equal(d.y_all.astype(np.int8), g["y_all"])
+    for m in ("train_mask", "val_mask", "test_mask"):
+        assert np.array_equal(getattr(d, m), g[m]), m
+    assert d.num_labels == g["num_labels"] and d.num_samples == g["n"]
+    assert int(d.train_mask.sum()) == {"cora": 140, "citeseer": 120}[name] and int(d.val_mask.sum()) == 500
+    # preprocessing order of the model plugin (reference H2GCN.py:46-54) reproduces the golden operands
+    d.row_normalize_features()
+    d.adj_remove_eye()
+    assert abs(sp.csr_matrix(d.features).astype(np.float32) - g["feat_rownorm"]).max() == 0
+    assert abs(sp.csr_matrix(d.sparse_adj) - g["adj_noeye"]).nnz == 0
+
+
+@pytest.mark.skipif(not __import__("pathlib").Path("/root/reference/baselines/gcn/gcn/data/ind.cora.x").exists(),
+                    reason="reference data files only exist in the build container")
+@pytest.mark.parametrize("name", ["cora", "citeseer"])
+def test_loader_on_the_reference_data_files(name):
+    g = load_planetoid_golden(name)
+    d = PlanetoidData(f"ind.{name}", "/root/reference/baselines/gcn/gcn/data", val_size=500)
+    a = sp.csr_matrix(d.sparse_adj); a.sort_indices()
+    assert (abs(a - g["adj_raw"])).nnz == 0
+    assert abs(sp.csr_matrix(d.features) - g["feat_raw"]).max() == 0
+    assert np.array_equal(d.y_all.astype(np.int8), g["y_all"])
+    for m in ("train_mask", "val_mask", "test_mask"):
+        assert np.array_equal(getattr(d, m), g[m]), m
+    assert str(sp.csr_matrix(d.features).dtype) == str(g["feat_raw"].dtype)
+
+
+def test_adjacency_from_lists_symmetrises_and_dedups():
+    a = adjacency_from_neighbour_lists({0: [1, 1, 2], 1: [0], 2: [2]})
+    assert a.toarray().tolist() == [[0, 1, 1], [1, 0, 0], [1, 0, 1]] and a.dtype == np.float32
+
+
+def test_metrics_known_answers():
+    preds = np.array([[2.0, 0.0], [0.0, 3.0], [1.0, 1.0], [5.0, -5.0], [0.0, 0.0]])
+    labels = np.array([[1, 0], [1, 0], [0, 1], [0, 1], [0, 0]], dtype=np.float64)
+    mask = np.array([1, 1, 1, 0, 1], dtype=bool)
+    lse = np.log(np.exp(preds).sum(1))
+    want = (-(preds[0, 0] - lse[0]) - (preds[1, 0] - lse[1]) - (preds[2, 1] - lse[2]) + 0.0) / 4
+    got = masked_softmax_cross_entropy(torch.tensor(preds), torch.tensor(labels), torch.tensor(mask)).item()
+    assert abs(got - want) < 1e-12 and abs(om.masked_softmax_cross_entropy(preds, labels, mask) - want) < 1e-12
+    acc = masked_accuracy(torch.tensor(preds), torch.tensor(labels), torch.tensor(mask)).item()
+    # rows 0 (correct), 1 (wrong), 2 (argmax tie -> class 0, wrong), 4 (all-zero label: argmax 0 == argmax 0)
+    assert abs(acc - 0.5) < 1e-12 and abs(om.masked_accuracy(preds, labels, mask) - 0.5) < 1e-12
+
+
+def test_early_stopping_window():
+    s = SlidingMeanEarlyStopping(3)
+    assert [s(v) for v in (1.0, 1.0, 1.0)] == [False] * 3
+    assert s(0.5) is False      # below the mean: enters the window
+    assert s(2.0) is True       # window full and above its mean
+    assert SlidingMeanEarlyStopping(0)(123.0) is False
+
+
+def test_argparse_hooks_run_dataset_first():
+    parser = arguments.create_parser()
+    order = []
+    parser.function_hooks["argparse"].append(lambda a: order.append("model"))
+    parser.function_hooks["argparse"].appendleft(lambda a: order.append("dataset"))
+    args = arguments.parse_args(parser, [])
+    assert order == ["dataset", "model"]
+    assert set(args.objects) >= {"pretrain_callbacks", "pre_epoch_callbacks", "post_epoch_callbacks", "post_train_callbacks"}
+
+
+def test_model_width_tracking_matches_oracle_forward():
+    from h2gcn_amd.models.H2GCN import H2GCN
+
+    for text, want in (("M64-R-T1-G-V-T2-G-V-C1-C2-D0.5-MO", 448), ("M64-R-T1-G-V-C1-D0.5-MO", 192),
+                       ("M64-R-D0.5-MO", 64), ("M-R-T1-G0-V-T2-G0_1-V-C1_2-S1_0_32-D-MO", 32)):
+        setup = parse_network_setup(text, 7, _dense_units=64, _dropout_rate=0.5)
+        m = H2GCN(setup, input_dim=30, n_hops=2)
+        assert m.layer_objs[-1].kernel.shape == (want, 7), text
+        # numpy interpreter agrees on the width feeding the output layer
+        rng = np.random.default_rng(0)
+        feats = sp.random(12, 30, 0.3, format="csr", random_state=0)
+        hops = [sp.random(12, 12, 0.3, format="csr", random_state=k) for k in (1, 2)]
+        weights = [rng.standard_normal(tuple(l.kernel.shape)) for l in m.regularized]
+        enc = [[k, {kk: ({"__set__": sorted(v)} if isinstance(v, set) else v) for kk, v in c.items()}] for k, c in setup]
+        assert om.forward(enc, feats, hops, weights).shape == (12, 7)

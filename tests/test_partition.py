@@ -61,6 +61,22 @@ def _worker(rank, world, port, n, d, out_dir):
         assert np.array_equal(x_full.numpy(), synth.synth_features_np(d, 3, 0, n))  # gathered == global
         y_local = og.gcn_layer_c(shard, x_full.numpy())
         np.save(Path(out_dir) / f"y{rank}.npy", y_local)
+
+        # the pipelined layer (feature chunks, per-chunk all-gather) with the oracle standing in for the HIP plan
+        from h2gcn_amd.partition import PipelinedHopAggregation
+
+        class OraclePlan:
+            n_rows, n_cols, n_hops = r1 - r0, n, 2
+
+            @staticmethod
+            def spmm(x, out):
+                out.copy_(torch.from_numpy(og.gcn_layer_c(shard, x.contiguous().numpy())))
+
+        for chunks in (1, 2, 4):
+            layer = PipelinedHopAggregation(OraclePlan, n, d, chunks, "cpu")
+            y_pipe = layer(x_local)
+            assert y_pipe.shape == (r1 - r0, 2, d)
+            assert np.array_equal(y_pipe.numpy(), y_local), chunks
         if rank == 0:  # single-process answer on the unpartitioned operands
             full = []
             for k, s in enumerate((1, 2)):
