@@ -73,7 +73,7 @@ struct LongList {
 struct h2gcn_plan {
     int n_hops = 0;
     int64_t n_rows = 0, n_cols = 0;
-    int long_threshold = 1024;
+    int long_threshold = 256;
     int rows_per_wave = 4;
     int variant = 0;
     int slice_cols = 0;  // 0 = heuristic

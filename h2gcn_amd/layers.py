@@ -122,3 +122,65 @@ class SliceLayer(torch.nn.Module):
         if self.tag:
             inputs = tagged[self.tag]
         return inputs[:, self.sliceObj]
+
+
+class _FusedPropagation(torch.autograd.Function):
+    """K rounds of hop aggregation written straight into the final concat buffer.
+
+    H2GCN-K's representation is ``[r_K | r_0 | r_1 | ... | r_{K-1}]`` with ``r_k = flatten(GCNLayer(r_{k-1}))``
+    (reference: ``G``/``V`` layers ``h2gcn/models/H2GCN.py:266-272,318-319`` followed by ``C<tag>`` concats,
+    ``_layers.py:90-96``; concat order = running input first, then tags in production order).  The reference
+    materialises every ``r_k`` (``tf.stack``), flattens, then copies everything twice more through ``ConcatV2``.
+    Here one ``[N, W]`` buffer is allocated; each round's fused SpMM reads ``r_{k-1}`` from its column slot
+    (row stride ``W``) and writes ``r_k`` into its own slot through the kernel's output strides -- no stack, no
+    flatten, no concat copy.  Backward walks the rounds in reverse with the adjoint launch, reading the incoming
+    gradient slots in place.
+    """
+
+    @staticmethod
+    def forward(ctx, r0: torch.Tensor, plan: HopPlan, rounds: int):
+        n, w0 = r0.shape
+        H = plan.n_hops
+        widths = [w0 * H ** k for k in range(rounds + 1)]
+        total = sum(widths)
+        # column offsets: r_K first, then r_0 .. r_{K-1}
+        off = [0] * (rounds + 1)
+        off[rounds] = 0
+        pos = widths[rounds]
+        for k in range(rounds):
+            off[k] = pos
+            pos += widths[k]
+        buf = torch.empty((n, total), dtype=torch.float32, device=r0.device)
+        buf[:, off[0]:off[0] + w0].copy_(r0)
+        for k in range(1, rounds + 1):
+            src = buf[:, off[k - 1]:off[k - 1] + widths[k - 1]]
+            dst = buf[:, off[k]:off[k] + widths[k]].unflatten(1, (H, widths[k - 1]))
+            plan.spmm(src, out=dst)
+        ctx.plan, ctx.rounds, ctx.widths, ctx.off = plan, rounds, widths, off
+        return buf
+
+    @staticmethod
+    def backward(ctx, grad: torch.Tensor):
+        plan, K, widths, off = ctx.plan, ctx.rounds, ctx.widths, ctx.off
+        H = plan.n_hops
+        g_k = grad[:, off[K]:off[K] + widths[K]]  # d r_K: a view, read in place by the adjoint launch
+        for k in range(K, 0, -1):
+            g_prev = plan.spmm_t(g_k.unflatten(1, (H, widths[k - 1])))
+            g_prev += grad[:, off[k - 1]:off[k - 1] + widths[k - 1]]
+            g_k = g_prev
+        return g_k, None, None
+
+
+def fused_propagation(plan: HopPlan, r0: torch.Tensor, rounds: int) -> torch.Tensor:
+    """``[r_K | r_0 | ... | r_{K-1}]`` for ``rounds = K`` aggregation rounds, without intermediate copies."""
+    if rounds < 1:
+        raise ValueError("rounds must be >= 1")
+    if r0.dim() != 2 or r0.shape[0] != plan.n_cols or plan.n_rows != plan.n_cols:
+        raise ValueError(f"r0 must be [{plan.n_cols}, d] and the hop matrices square")
+    if r0.requires_grad and torch.is_grad_enabled():
+        return _FusedPropagation.apply(r0, plan, rounds)
+    return _FusedPropagation.forward(_NoCtx(), r0, plan, rounds)
+
+
+class _NoCtx:
+    pass

@@ -245,18 +245,64 @@ class H2GCN(torch.nn.Module):
                 self.tags[ind] = tag
                 tag_width[tag] = width
         self.output_width = width
+        self.fused = self._find_fusable_block(layer_setups, n_hops)
 
-    def forward(self, adj, inputs, adjhops, return_before: int = 0, execute_after: int = 0, tagged_out: dict = None):
+    @staticmethod
+    def _find_fusable_block(layer_setups, n_hops):
+        """Locate ``<X>-T a_1 -G-V-T a_2 -G-V ... -C a_1 -C a_2 ...`` (the H2GCN-K propagation: K unfiltered G-V
+        rounds whose inputs are tagged in order, immediately followed by the K matching concats).  Returns
+        ``(first_G, end, K, tags)`` -- layers ``first_G .. end-1`` are then replaced by one fused launch sequence
+        writing into the final concat buffer -- or None."""
+        kinds = [k for k, _ in layer_setups]
+        confs = [c for _, c in layer_setups]
+        for start in range(1, len(kinds)):
+            if kinds[start] != Layer.GCN or "tag" not in confs[start - 1]:
+                continue
+            K, i, tags = 0, start, [confs[start - 1]["tag"]]
+            while i + 1 < len(kinds) and kinds[i] == Layer.GCN and confs[i].get("hops") is None and kinds[i + 1] == Layer.VECTORIZE:
+                K += 1
+                i += 2
+                if "tag" in confs[i - 1]:
+                    tags.append(confs[i - 1]["tag"])
+                else:
+                    break
+            if K == 0 or len(tags) != K or len(set(tags)) != K:
+                continue
+            ok = all(i + j < len(kinds) and kinds[i + j] == Layer.CONCAT and confs[i + j]["tags"] == [tags[j]]
+                     and confs[i + j].get("addInputs", True) and "tag" not in confs[i + j] for j in range(K))
+            later_use = any(kinds[m] in (Layer.CONCAT, Layer.SLICE) for m in range(i + K, len(kinds)))
+            if ok and not later_use and n_hops >= 1:
+                return (start, i + K, K, tags)
+        return None
+
+    def forward(self, adj, inputs, adjhops, return_before: int = 0, execute_after: int = 0, tagged_out: dict = None,
+                fuse: bool = True):
         n_layers = len(self.layer_objs)
         if return_before <= 0:
             return_before = n_layers + return_before
         if execute_after < 0:
             execute_after = n_layers + execute_after
         tagged = {}
+        skip_until = 0
         for ind, layer in enumerate(self.layer_objs):
             if ind == return_before:
                 return inputs
             if ind < execute_after:
+                continue
+            if fuse and self.fused is not None and ind == self.fused[0] and not (ind < return_before < self.fused[1]) \
+                    and adjhops.n_rows == adjhops.n_cols:
+                # concat-free propagation: layers fused[0] .. fused[1]-1 in one go
+                _, end, K, tags = self.fused
+                inputs = L.fused_propagation(adjhops, inputs, K)
+                skip_until = end
+                w0 = tagged[tags[0]].shape[1]
+                H = adjhops.n_hops
+                pos = w0 * H ** K
+                for k in range(1, K):  # expose r_1 .. r_{K-1} under their tags as views of the buffer
+                    pos += w0 * H ** (k - 1)
+                    tagged[tags[k]] = inputs[:, pos:pos + w0 * H ** k]
+                continue
+            if ind < skip_until:
                 continue
             if ind in self.concat_inds:
                 inputs = layer(inputs, **tagged)

@@ -160,3 +160,44 @@ class PipelinedHopAggregation:
             main.wait_event(self.ready[c])
             self._spmm(self.full[c][: self.n], out[:, :, c * dc:(c + 1) * dc])
         return out
+
+
+def _reduce_scatter_rows(full: torch.Tensor, per: int, rank: int, group=None) -> torch.Tensor:
+    """Sum ``full`` ([P*per, d]) over ranks and return this rank's block of ``per`` rows.  RCCL: one
+    ``ncclReduceScatter``; gloo (CPU tests) has no reduce-scatter, so all-reduce + slice."""
+    if dist.get_backend(group) == "gloo":
+        dist.all_reduce(full, group=group)
+        return full[rank * per:(rank + 1) * per].clone()
+    out = torch.empty((per, full.shape[1]), dtype=full.dtype, device=full.device)
+    dist.reduce_scatter_tensor(out, full, group=group)
+    return out
+
+
+class _ShardedHopSpMM(torch.autograd.Function):
+    """Row-sharded GCNLayer with autograd: forward = all-gather(X) + local fused SpMM (pipelined); backward = the
+    adjoint on the local shard, which yields a full-height contribution ``A_k[rows_p, :]^T dY_p``, summed across
+    ranks and scattered back to the row owners (reduce-scatter: the mirror image of the forward all-gather,
+    SURVEY.md §8e)."""
+
+    @staticmethod
+    def forward(ctx, x_local, layer):
+        ctx.layer = layer
+        return layer(x_local)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        layer = ctx.layer
+        dx_full = layer.plan.spmm_t(grad_y.contiguous())  # [N, d]
+        if layer.world == 1:
+            return dx_full, None
+        padded = torch.zeros((layer.world * layer.per, layer.d), dtype=dx_full.dtype, device=dx_full.device)
+        padded[: layer.n] = dx_full
+        mine = _reduce_scatter_rows(padded, layer.per, layer.rank, layer.group)
+        return mine[: layer.r1 - layer.r0], None
+
+
+def sharded_hop_spmm(layer: "PipelinedHopAggregation", x_local: torch.Tensor) -> torch.Tensor:
+    """Differentiable row-sharded hop aggregation: ``[n_local, d] -> [n_local, H, d]``."""
+    if x_local.requires_grad and torch.is_grad_enabled():
+        return _ShardedHopSpMM.apply(x_local, layer)
+    return layer(x_local)

@@ -60,7 +60,7 @@ typedef struct h2gcn_plan_opts {
     uint32_t struct_size;        /* = sizeof(h2gcn_plan_opts), for forward compatibility                   */
     uint32_t flags;              /* H2GCN_PLAN_*                                                            */
     int32_t long_row_threshold;  /* (row,hop) segments with >= this many nonzeros are split across the
-                                    waves of one workgroup (LDS-staged partial sums); default 1024         */
+                                    waves of one workgroup (LDS-staged partial sums); default 256          */
     int32_t rows_per_wave;       /* consecutive rows a wave walks in the regular path; default 4           */
     int32_t variant;             /* kernel variant selector, 0 = default                   */
     int32_t slice_cols;          /* feature columns per slice of the slice-major schedule: 32/64/128/256,

@@ -89,6 +89,28 @@ def test_gradients_match_dense_float64_replica(tmp_path):
         assert (got.cpu().double() - want).abs().max().item() <= 1e-6 + 1e-4 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("network", [H2GCN2, "M64-R-T1-G-V-C1-D0.5-MO", "M64-R-T1-G-V-T2-G-V-T3-G-V-C1-C2-C3-MO"])
+def test_concat_free_propagation_equals_generic_interpreter(tmp_path, network):
+    """hop outputs written straight into the [N, W] concat buffer (no stack / flatten /
+    concat copies) give the same bits as the layer-by-layer interpreter, and the same gradients."""
+    g, data, tensors, setup, model = _setup(tmp_path, network)
+    assert model.fused is not None
+    model.eval()
+    args = (tensors["adj"], tensors["features"], tensors["adj_hops"])
+    tg_f, tg_g = {}, {}
+    y_f = model(*args, tagged_out=tg_f)
+    gf = torch.autograd.grad(model.loss(y_f, tensors["y_train"], tensors["train_mask"]), list(model.parameters()))
+    y_g = model(*args, tagged_out=tg_g, fuse=False)
+    gg = torch.autograd.grad(model.loss(y_g, tensors["y_train"], tensors["train_mask"]), list(model.parameters()))
+    assert torch.equal(y_f, y_g)
+    assert set(tg_f) == set(tg_g) and all(torch.equal(tg_f[k], tg_g[k]) for k in tg_f)
+    for a, b in zip(gf, gg):
+        assert (a - b).abs().max().item() <= 1e-6 + 1e-5 * b.abs().max().item()
+    # the fused buffer really is [r_K | r_0 | ... ]: embeddings before the output layer
+    emb = model(*args, return_before=-1)
+    assert emb.shape[1] == model.layer_objs[-1].kernel.shape[0]
+
+
 def test_entry_point_trains_cora(tmp_path, capsys):
     """`run_experiments H2GCN planetoid --dataset ind.cora ...` (reference README usage): loss falls, validation
     accuracy reaches the usual band for H2GCN-2 on Cora (sanity, not a target)."""

@@ -72,11 +72,30 @@ def _worker(rank, world, port, n, d, out_dir):
             def spmm(x, out):
                 out.copy_(torch.from_numpy(og.gcn_layer_c(shard, x.contiguous().numpy())))
 
+            @staticmethod
+            def spmm_t(grad):
+                return torch.from_numpy(og.gcn_layer_grad_c(shard, grad.numpy(), n))
+
         for chunks in (1, 2, 4):
             layer = PipelinedHopAggregation(OraclePlan, n, d, chunks, "cpu")
             y_pipe = layer(x_local)
             assert y_pipe.shape == (r1 - r0, 2, d)
             assert np.array_equal(y_pipe.numpy(), y_local), chunks
+
+        # distributed backward: adjoint on the shard + reduce-scatter == rows [r0, r1) of the global adjoint
+        from h2gcn_amd.partition import sharded_hop_spmm
+
+        w_full = synth.synth_features_np(2 * d, 9, 0, n).reshape(n, 2, d)
+        xl = x_local.clone().requires_grad_(True)
+        layer = PipelinedHopAggregation(OraclePlan, n, d, 2, "cpu")
+        (sharded_hop_spmm(layer, xl) * torch.from_numpy(w_full[r0:r1])).sum().backward()
+        np.save(Path(out_dir) / f"dx{rank}.npy", xl.grad.numpy())
+        if rank == 0:
+            full_ops = []
+            for k, s in enumerate((1, 2)):
+                rp, ci, va = synth.synth_hop_rows_np(degs[k], n, s, 0, n)
+                full_ops.append(sp.csr_matrix((va, ci, rp), shape=(n, n)))
+            np.save(Path(out_dir) / "dx_full.npy", og.gcn_layer_grad_c(full_ops, w_full, n))
         if rank == 0:  # single-process answer on the unpartitioned operands
             full = []
             for k, s in enumerate((1, 2)):
@@ -97,3 +116,6 @@ def test_row_partition_allgather_equals_single_rank(world, n, tmp_path):
     parts = [np.load(tmp_path / f"y{r}.npy") for r in range(world)]
     full = np.load(tmp_path / "full.npy")
     assert np.array_equal(np.concatenate(parts, 0), full)  # bit-for-bit: partitioning never changes arithmetic
+    dx = np.concatenate([np.load(tmp_path / f"dx{r}.npy") for r in range(world)], 0)
+    want = np.load(tmp_path / "dx_full.npy")
+    assert dx.shape == want.shape and np.abs(dx - want).max() <= 1e-5  # sum over ranks re-associates the adjoint

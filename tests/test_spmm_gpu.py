@@ -134,7 +134,7 @@ def test_all_empty_and_zero_nnz():
 @pytest.mark.parametrize("threshold", [0, 8, 64, 70])
 def test_long_rows_split_across_the_workgroup(d, threshold):
     """One huge row (5000 nnz), a few medium ones, many short: exercises the LDS-staged long-segment path
-    (threshold 0 = library default 1024; small thresholds push most rows through it)."""
+    (threshold 0 = library default 256; small thresholds push most rows through it)."""
     rng = np.random.default_rng(9)
     n = 6000
     deg = rng.integers(0, 12, n)
