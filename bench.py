@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--slice-cols", type=int, default=0, help="feature columns per slice (0 = library heuristic)")
     ap.add_argument("--chunks", type=int, default=-1,
                     help="feature chunks of the pipelined all-gather/SpMM (default: 1 on one GPU, 4 on several)")
+    ap.add_argument("--adjoint", action="store_true", help="also time the backward (adjoint) launch; extra, not the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
@@ -130,7 +131,7 @@ def main():
     torch.cuda.synchronize()
     plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n,
                    variant=a.variant, long_row_threshold=a.long_row_threshold, rows_per_wave=a.rows_per_wave,
-                   slice_cols=a.slice_cols)
+                   slice_cols=a.slice_cols, build_transpose=a.adjoint)
     x_local = synth.synth_features(d, synth.SEED_X, r0, r1, device)
     chunks = a.chunks if a.chunks > 0 else (1 if world == 1 else 4)
     layer = PipelinedHopAggregation(plan, n, d, chunks, device)
@@ -210,6 +211,21 @@ def main():
             "algorithmic_bytes_per_launch": b_alg,
         },
     }
+    if a.adjoint:
+        # backward launch dX = sum_k A_k^T dY[:, k, :] on the local shard (secondary figure, untimed by the metric)
+        dy = synth.synth_features(2 * d, 77, r0, r1, device).view(r1 - r0, 2, d)
+        for _ in range(3):
+            plan.spmm_t(dy)
+        evs = []
+        for _ in range(10):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); plan.spmm_t(dy); e.record()
+            evs.append((s, e))
+        torch.cuda.synchronize()
+        adj_ms = float(np.mean([s.elapsed_time(e) for s, e in evs]))
+        b_adj = sum(z * (4 + 4 + 4 * d) + (n + 1) * 8 for z in nnz_local) + n * d * 4
+        out["adjoint"] = {"kernel_ms": adj_ms, "algorithmic_bytes_per_launch": b_adj,
+                          "achieved_GBps": b_adj / (adj_ms * 1e-3) / 1e9, "frac": b_adj / (adj_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(csr, x_local, d, a.cpu_seconds)

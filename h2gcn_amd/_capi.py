@@ -24,6 +24,7 @@ ERR_INTERNAL = -6
 
 PLAN_BUILD_TRANSPOSE = 0x1
 PLAN_SKIP_VALIDATION = 0x2
+PLAN_HOST_TRANSPOSE = 0x4
 
 #: every symbol include/h2gcn_hip.h declares (tests check the built library exports all of them)
 EXPORTED_SYMBOLS = (

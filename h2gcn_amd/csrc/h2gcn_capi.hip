@@ -87,6 +87,12 @@ struct h2gcn_plan {
     mutable std::map<uint64_t, LongList> long_cache;  // key = mask | (adjoint << 32)
 };
 
+namespace h2gcn {
+int transpose_csr_device(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
+                         const float* vals, int64_t** t_rowptr_out, int32_t** t_colidx_out, float** t_vals_out,
+                         hipStream_t stream, std::string* err);
+}
+
 namespace {
 
 using h2gcn::HopCsr;
@@ -324,34 +330,55 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
             plan->adj.resize(n_hops);
             for (int k = 0; k < n_hops; ++k) {
                 const int64_t nnz = plan->fwd[k].nnz;
-                std::vector<int32_t> h_col(nnz);
-                std::vector<float> h_val(nnz);
-                if (nnz > 0) {
-                    H2GCN_HIP_TRY(hipMemcpy(h_col.data(), colidx_dev[k], nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
-                    H2GCN_HIP_TRY(hipMemcpy(h_val.data(), vals_dev[k], nnz * sizeof(float), hipMemcpyDeviceToHost));
-                }
-                std::vector<int64_t> t_rowptr;
-                std::vector<int32_t> t_col;
-                std::vector<float> t_val;
-                transpose_csr_host(n_rows, n_cols, h_rowptr[k], h_col, h_val, t_rowptr, t_col, t_val);
-                plan->owned.emplace_back();
-                DeviceBuf& d_rp = plan->owned.back();
-                H2GCN_HIP_TRY(hipMalloc(&d_rp.p, (n_cols + 1) * sizeof(int64_t)));
-                H2GCN_HIP_TRY(hipMemcpy(d_rp.p, t_rowptr.data(), (n_cols + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-                plan->owned.emplace_back();
-                DeviceBuf& d_ci = plan->owned.back();
-                plan->owned.emplace_back();
-                DeviceBuf& d_va = plan->owned.back();
-                if (nnz > 0) {
-                    H2GCN_HIP_TRY(hipMalloc(&d_ci.p, nnz * sizeof(int32_t)));
-                    H2GCN_HIP_TRY(hipMemcpy(d_ci.p, t_col.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
-                    H2GCN_HIP_TRY(hipMalloc(&d_va.p, nnz * sizeof(float)));
-                    H2GCN_HIP_TRY(hipMemcpy(d_va.p, t_val.data(), nnz * sizeof(float), hipMemcpyHostToDevice));
+                int64_t* t_rp = nullptr;
+                int32_t* t_ci = nullptr;
+                float* t_va = nullptr;
+                std::vector<int64_t> t_rowptr(n_cols + 1);
+                std::string terr;
+                int st = (o.flags & H2GCN_PLAN_HOST_TRANSPOSE)
+                             ? -1
+                             : h2gcn::transpose_csr_device(n_rows, n_cols, nnz, rowptr_dev[k], colidx_dev[k], vals_dev[k],
+                                                           &t_rp, &t_ci, &t_va, stream, &terr);
+                if (st == 0) {
+                    plan->owned.emplace_back(); plan->owned.back().p = t_rp;
+                    plan->owned.emplace_back(); plan->owned.back().p = t_ci;
+                    plan->owned.emplace_back(); plan->owned.back().p = t_va;
+                    H2GCN_HIP_TRY(hipMemcpy(t_rowptr.data(), t_rp, (n_cols + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+                } else if (st == -3) {
+                    return fail(H2GCN_ERR_OUT_OF_MEMORY, "transposition of hop %d: %s", k, terr.c_str());
+                } else {
+                    // host path: requested explicitly, or the device path declined (>= 2^32 nonzeros)
+                    std::vector<int32_t> h_col(nnz);
+                    std::vector<float> h_val(nnz);
+                    if (nnz > 0) {
+                        H2GCN_HIP_TRY(hipMemcpy(h_col.data(), colidx_dev[k], nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+                        H2GCN_HIP_TRY(hipMemcpy(h_val.data(), vals_dev[k], nnz * sizeof(float), hipMemcpyDeviceToHost));
+                    }
+                    std::vector<int32_t> t_col;
+                    std::vector<float> t_val;
+                    transpose_csr_host(n_rows, n_cols, h_rowptr[k], h_col, h_val, t_rowptr, t_col, t_val);
+                    plan->owned.emplace_back();
+                    DeviceBuf& d_rp = plan->owned.back();
+                    H2GCN_HIP_TRY(hipMalloc(&d_rp.p, (n_cols + 1) * sizeof(int64_t)));
+                    H2GCN_HIP_TRY(hipMemcpy(d_rp.p, t_rowptr.data(), (n_cols + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+                    plan->owned.emplace_back();
+                    DeviceBuf& d_ci = plan->owned.back();
+                    plan->owned.emplace_back();
+                    DeviceBuf& d_va = plan->owned.back();
+                    if (nnz > 0) {
+                        H2GCN_HIP_TRY(hipMalloc(&d_ci.p, nnz * sizeof(int32_t)));
+                        H2GCN_HIP_TRY(hipMemcpy(d_ci.p, t_col.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+                        H2GCN_HIP_TRY(hipMalloc(&d_va.p, nnz * sizeof(float)));
+                        H2GCN_HIP_TRY(hipMemcpy(d_va.p, t_val.data(), nnz * sizeof(float), hipMemcpyHostToDevice));
+                    }
+                    t_rp = (int64_t*)d_rp.p;
+                    t_ci = (int32_t*)d_ci.p;
+                    t_va = (float*)d_va.p;
                 }
                 HopOperand& op = plan->adj[k];
-                op.rowptr = (const int64_t*)d_rp.p;
-                op.colidx = (const int32_t*)d_ci.p;
-                op.vals = (const float*)d_va.p;
+                op.rowptr = t_rp;
+                op.colidx = t_ci;
+                op.vals = t_va;
                 op.nnz = nnz;
                 collect_long_rows(t_rowptr, n_cols, plan->long_threshold, op.long_rows);
             }

@@ -37,7 +37,7 @@ class HopPlan:
     def __init__(self, rowptr: Sequence[torch.Tensor], colidx: Sequence[torch.Tensor],
                  vals: Sequence[torch.Tensor], n_cols: int, *, build_transpose: bool = False,
                  long_row_threshold: int = 0, rows_per_wave: int = 0, variant: int = 0,
-                 slice_cols: int = 0, validate: bool = True):
+                 slice_cols: int = 0, validate: bool = True, host_transpose: bool = False):
         H = len(rowptr)
         _require(1 <= H <= _capi.MAX_HOPS, f"need 1..{_capi.MAX_HOPS} hop matrices, got {H}")
         _require(len(colidx) == H and len(vals) == H, "rowptr/colidx/vals lists differ in length")
@@ -71,7 +71,8 @@ class HopPlan:
         va_a = arr_t(*[t.data_ptr() for t in self.vals])
         opts = _capi.PlanOpts()
         opts.struct_size = C.sizeof(_capi.PlanOpts)
-        opts.flags = (_capi.PLAN_BUILD_TRANSPOSE if build_transpose else 0) | (0 if validate else _capi.PLAN_SKIP_VALIDATION)
+        opts.flags = ((_capi.PLAN_BUILD_TRANSPOSE if build_transpose else 0) | (0 if validate else _capi.PLAN_SKIP_VALIDATION)
+                      | (_capi.PLAN_HOST_TRANSPOSE if host_transpose else 0))
         opts.long_row_threshold = int(long_row_threshold)
         opts.rows_per_wave = int(rows_per_wave)
         opts.variant = int(variant)

@@ -54,6 +54,8 @@ typedef enum h2gcn_status {
 /* flags for h2gcn_plan_opts.flags */
 #define H2GCN_PLAN_BUILD_TRANSPOSE 0x1u /* also build A_k^T (needed by h2gcn_spmm_hops_T_f32)               */
 #define H2GCN_PLAN_SKIP_VALIDATION 0x2u /* skip the one-time column-range check on the device               */
+#define H2GCN_PLAN_HOST_TRANSPOSE  0x4u /* build A_k^T with the host counting sort instead of the device radix
+                                           sort (debug / cross-check; same result)                            */
 
 /* Tunables of the CSR-adaptive schedule.  Zero in a field means "library default". */
 typedef struct h2gcn_plan_opts {

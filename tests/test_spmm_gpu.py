@@ -244,6 +244,19 @@ def test_adjoint_matches_oracle(d):
     assert np.abs(dx1 - og.gcn_layer_grad_c(hops[1:], dy[:, 1:2].copy(), 500)).max() <= 2e-5
 
 
+def test_device_and_host_transposition_agree():
+    """The device radix-sort transposition and the host counting sort build the same canonical A^T: the adjoint
+    launch gives identical bits on either."""
+    from h2gcn_amd import HopPlan
+
+    hops = [rand_csr(1500, 900, 0.03, 1, empty_frac=0.1), rand_csr(1500, 900, 0.08, 2), sp.csr_matrix((1500, 900), dtype=np.float32)]
+    dy = torch.from_numpy(np.random.default_rng(2).uniform(-1, 1, (1500, 3, 64)).astype(np.float32)).to(dev())
+    a = HopPlan.from_scipy(hops, dev(), build_transpose=True).spmm_t(dy)
+    b = HopPlan.from_scipy(hops, dev(), build_transpose=True, host_transpose=True).spmm_t(dy)
+    assert torch.equal(a, b)
+    assert np.abs(a.cpu().numpy() - og.gcn_layer_grad_c(hops, dy.cpu().numpy(), 900)).max() <= 2e-5
+
+
 def test_autograd_through_gcn_layer():
     from h2gcn_amd import GCNLayer, HopPlan
 
@@ -342,6 +355,14 @@ def test_baseline_shapes_properties(shape):
     y2 = plan.spmm(2 * x + ones)
     assert (y2 - (2 * y + y1)).abs().max().item() <= 1e-4
     del y1, y2, ones
+    # (2b) adjoint identity <A x, w> == <x, A^T w> with the device-built transposed operands
+    plan_t = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n, build_transpose=True)
+    w = synth.synth_features(2 * d, 77, 0, n, device).view(n, 2, d)
+    dx = plan_t.spmm_t(w)
+    lhs = (y.double() * w.double()).sum().item()
+    rhs = (x.double() * dx.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs), (y.double().abs() * w.double().abs()).sum().item() * 1e-3)
+    del plan_t, w, dx
     # (3) sampled rows vs the oracle on independently regenerated operands
     rng = np.random.default_rng(0)
     blocks = [0, n - 8] + list(rng.integers(0, n - 8, 6))
