@@ -34,6 +34,11 @@ def algorithmic_bytes(nnz_list, n_rows_out, d, n_hops):
     return sum(z * (4 + 4 + 4 * d) + (n_rows_out + 1) * 8 for z in nnz_list) + n_rows_out * n_hops * d * 4
 
 
+def compulsory_bytes(nnz_list, n_rows_out, n_cols, d, n_hops):
+    """Lower bound with perfect reuse of X (SURVEY.md §8d `B_min`): every index/value once, X once, Y once."""
+    return sum(z * 8 + (n_rows_out + 1) * 8 for z in nnz_list) + n_cols * d * 4 + n_rows_out * n_hops * d * 4
+
+
 def pmc_traffic(shape, d, chunks, slice_cols, world):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
     see profiles/*_summary.json); bench.py cannot collect counters itself, so this is null for any
@@ -78,12 +83,28 @@ def cpu_baseline(plan_csr, x_full, d, target_seconds=12.0):
     t = time.perf_counter()
     og.gcn_layer_c(parts, x_cpu)
     dt = time.perf_counter() - t
-    return {
+    res = {
         "value": edges / dt, "unit": "edges/s", "cores": 1, "kind": "port",
         "sample": f"rows [0,{n1}) of the same operands: {edges} aggregated edges, d={d}, {dt:.1f} s, "
                   f"oracle/spmm_oracle.c (plain C, -O2, 1 thread; host has {os.cpu_count()} cores)",
         "calibration_edges_per_s": rate,
     }
+    # second reported baseline (SURVEY.md §8d ii): torch's CPU CSR @ dense on all host threads, same sample
+    try:
+        xt = torch.from_numpy(x_cpu)
+        mats = [torch.sparse_csr_tensor(torch.from_numpy(p[0]), torch.from_numpy(p[1].astype(np.int64)),
+                                        torch.from_numpy(p[2]), size=(n1, x_cpu.shape[0])) for p in parts]
+        for m in mats:
+            m @ xt  # warm-up
+        t = time.perf_counter()
+        for m in mats:
+            m @ xt
+        dt2 = time.perf_counter() - t
+        res["torch_cpu_all_threads"] = {"value": edges / dt2, "unit": "edges/s", "threads": torch.get_num_threads(),
+                                        "seconds": dt2, "what": "torch.sparse_csr_tensor @ dense, same sample"}
+    except Exception as e:
+        res["torch_cpu_all_threads"] = {"value": None, "error": str(e)}
+    return res
 
 
 def main():
@@ -209,6 +230,7 @@ def main():
             "kernel": "h2gcn::spmm_hops_kernel (fused 1+2-hop)" + (f", {chunks} launches of d/{chunks} columns" if chunks > 1 else ""),
             "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_max,
             "algorithmic_bytes_per_launch": b_alg,
+            "compulsory_bytes_per_launch": compulsory_bytes(nnz_local, r1 - r0, n, d, 2),
         },
     }
     if a.adjoint:

@@ -16,10 +16,6 @@ dropout, ``G`` / ``G0_1`` hop aggregation (optional hop filter), ``C<tag>_<tag>`
 """
 from __future__ import annotations
 
-import contextlib
-import importlib
-import os
-import pkgutil
 import re
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -110,17 +106,12 @@ def parse_network_setup(network_setup_str: str, output_dim: int, _dense_units: O
 
 def add_subparsers(parser):
     """Positional ``model`` + the chosen model's own flags (reference ``:16-31``)."""
-    model_list = [m.name for m in pkgutil.iter_modules(path=__path__) if not m.name.startswith("_")]
-    parser.add_argument("model", choices=model_list, help="Network model selected for experiment")
-    try:
-        with open(os.devnull, "w") as devnull, contextlib.redirect_stderr(devnull):
-            known, _ = parser.parse_known_args()
-    except SystemExit:
-        return
-    module = importlib.import_module("." + known.model, package=__name__)
-    if hasattr(module, "add_subparser_args"):
-        module.add_subparser_args(parser)
-        print(f"Using model: {module}")
+    import sys
+
+    from .._plugins import register_positional
+
+    return register_positional(parser, sys.modules[__name__], "model", "Network model selected for experiment",
+                               announce=True)
 
 
 def toNumpy(x):

@@ -1,10 +1,13 @@
-"""Argument parser with a hook deque (reference ``h2gcn/modules/arguments.py:5-41``).
+"""Argument parser carrying a hook queue (reference ``h2gcn/modules/arguments.py:5-41``).
 
-Plugins append callables to ``parser.function_hooks["argparse"]``; ``parse_args`` parses, creates the callback
-deques in ``args.objects`` and runs the hooks in order (the dataset plugin registers with ``appendleft`` so that it
-runs before the model plugin)."""
+Contract kept from the reference: plugins register callables in ``parser.function_hooks["argparse"]`` (a deque:
+``append`` = run later, ``appendleft`` = run first); after the command line is parsed, ``args.objects`` is created
+with the four callback queues the epoch driver consumes, and the hooks run front to back, each receiving ``args``.
+signac job bookkeeping (``--use_signac``) is not carried over."""
 import argparse
 from collections import deque
+
+CALLBACK_QUEUES = ("pretrain_callbacks", "pre_epoch_callbacks", "post_epoch_callbacks", "post_train_callbacks")
 
 
 def create_parser() -> argparse.ArgumentParser:
@@ -14,15 +17,15 @@ def create_parser() -> argparse.ArgumentParser:
 
 
 def parse_args(parser: argparse.ArgumentParser, argv=None):
-    parser.add_argument("--verbose", "-v", action="store_true")
-    parser.add_argument("--help", "-h", action="help")
-    parser.add_argument("--exp_tags", default=[], nargs="+", dest="_exp_tags")
+    common = parser.add_argument_group("Common arguments")
+    common.add_argument("--verbose", "-v", action="store_true")
+    common.add_argument("--help", "-h", action="help")
+    common.add_argument("--exp_tags", nargs="+", default=[], dest="_exp_tags")
     args = parser.parse_args(argv)
-    args.use_signac = False  # signac bookkeeping is out of scope; kept as an attribute the plugins may test
-    args.objects = dict(function_hooks=parser.function_hooks)
-    for name in ("pretrain_callbacks", "pre_epoch_callbacks", "post_epoch_callbacks", "post_train_callbacks"):
-        args.objects[name] = deque()
-    hooks = parser.function_hooks["argparse"]
-    while hooks:
-        hooks.popleft()(args)
+    args.use_signac = False
+    args.objects = {"function_hooks": parser.function_hooks, **{name: deque() for name in CALLBACK_QUEUES}}
+    pending = parser.function_hooks["argparse"]
+    while pending:
+        hook = pending.popleft()
+        hook(args)
     return args

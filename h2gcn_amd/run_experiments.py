@@ -37,24 +37,32 @@ def main(argv=None):
     logger.add_subparser_args(parser)
     args = arguments.parse_args(parser)
 
-    for func in args.objects["pretrain_callbacks"]:
-        func(**args.objects["tensors"])
-
-    t0 = time.perf_counter()
-    args.current_epoch = 0
-    while args.current_epoch < args.epochs:
-        args.current_epoch += 1
-        for func in args.objects["pre_epoch_callbacks"]:
-            func(args.current_epoch, args)
-        args.objects["epoch_stats"] = dict()
-        args.objects["epoch_stats"].update(args.objects["train_step"](**args.objects["tensors"]))
-        args.objects["epoch_stats"].update(args.objects["test_step"](**args.objects["tensors"]))
-        for func in args.objects["post_epoch_callbacks"]:
-            func(args.current_epoch, args)
-        while args.current_epoch >= args.epochs and len(args.objects["post_train_callbacks"]) > 0:
-            args.objects["post_train_callbacks"].popleft()(args)
-    args.objects["wall_seconds"] = time.perf_counter() - t0
+    run_epochs(args)
     return args
+
+
+def run_epochs(args):
+    """The epoch driver (reference ``run_experiments.py:44-61``): pre-train callbacks once; per epoch the
+    pre-epoch callbacks, one train step and one test step (their dicts merged into ``args.objects["epoch_stats"]``)
+    and the post-epoch callbacks; post-train callbacks once the (possibly early-stopped) last epoch is done."""
+    obj = args.objects
+    tensors = obj["tensors"]
+    for callback in obj["pretrain_callbacks"]:
+        callback(**tensors)
+    started = time.perf_counter()
+    epoch = 0
+    while epoch < args.epochs:  # args.epochs may be lowered by the early-stopping callback
+        epoch += 1
+        args.current_epoch = epoch
+        for callback in obj["pre_epoch_callbacks"]:
+            callback(epoch, args)
+        obj["epoch_stats"] = {**obj["train_step"](**tensors), **obj["test_step"](**tensors)}
+        for callback in obj["post_epoch_callbacks"]:
+            callback(epoch, args)
+    queue = obj["post_train_callbacks"]
+    while queue:
+        queue.popleft()(args)
+    obj["wall_seconds"] = time.perf_counter() - started
 
 
 if __name__ == "__main__":

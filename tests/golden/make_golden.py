@@ -20,6 +20,7 @@ Fixtures
                          labels/masks, and the SYM- and RW-normalised exact-1-hop / exact-2-hop matrices.
 * citeseer_operands.npz  same for ind.citeseer (isolated nodes -> rows with no neighbours: the inf->0 branch).
 * dsl_parse.json         parse_network_setup() output for the network strings used by the reference configs.
+* cora_layer_outputs.npz r1 / r2 of H2GCN-2 on the golden Cora operands (row subset + fp64 column sums), via scipy.
 * syn_products.npz       one graph from the reference generator (n=10000, 10 classes, m=6, h=0.2) as CSR.
 """
 import argparse
@@ -115,6 +116,27 @@ def planetoid_fixture(ref, name):
     print(name, "nnz per split", out["split_nnz"], "bytes", (HERE / f"{name.split('.')[-1]}_operands.npz").stat().st_size)
 
 
+def layer_output_fixture():
+    """r1 = [A1 X | A2 X], r2 = [A1 r1 | A2 r1] on the golden Cora SYM operands for
+    X = PCG64(123) U(-1,1) [2708, 64] (regenerated by the tests, not stored): fp32 rows of a fixed subset (first,
+    last, max-degree row, empty 2-hop rows, a few more) + fp64 column sums of all rows.  Computed with scipy's
+    csr @ dense directly (the loop nest TF's CPU kernel has), independently of oracle/."""
+    z = np.load(HERE / "cora_operands.npz")
+    n = len(z["hop1_sym_indptr"]) - 1
+    hops = [sp.csr_matrix((z[f"hop{k}_sym_data"], z[f"hop{k}_sym_indices"], z[f"hop{k}_sym_indptr"]), shape=(n, n)) for k in (1, 2)]
+    x = np.random.Generator(np.random.PCG64(123)).uniform(-1, 1, (n, 64)).astype(np.float32)
+    r1 = np.concatenate([h.astype(np.float32) @ x for h in hops], 1)
+    r2 = np.concatenate([h.astype(np.float32) @ r1 for h in hops], 1)
+    r1_64 = np.concatenate([h.astype(np.float64) @ x.astype(np.float64) for h in hops], 1)
+    r2_64 = np.concatenate([h.astype(np.float64) @ r1_64 for h in hops], 1)
+    deg1, deg2 = np.diff(hops[0].indptr), np.diff(hops[1].indptr)
+    rows = sorted(set([0, 1, n - 1, int(deg1.argmax()), int(deg2.argmax())] + np.where(deg2 == 0)[0][:8].tolist()
+                      + list(range(100, 2700, 53))))
+    np.savez_compressed(HERE / "cora_layer_outputs.npz", rows=np.array(rows), r1_rows=r1[rows], r2_rows=r2[rows],
+                        r1_colsum64=r1_64.sum(0), r2_colsum64=r2_64.sum(0))
+    print("layer outputs: rows", len(rows))
+
+
 def dsl_fixture():
     sys.modules.setdefault("tensorflow", types.ModuleType("tensorflow"))
     # `from modules import logger` inside models/__init__.py needs h2gcn/ on the path and a stub logger
@@ -185,6 +207,7 @@ def main():
     planetoid_fixture(ref, "ind.cora")
     planetoid_fixture(ref, "ind.citeseer")
     dsl_fixture()
+    layer_output_fixture()
     if a.syn:
         make_syn(syn_fixture())
 

@@ -64,6 +64,39 @@ def test_forward_matches_oracle_interpreter(tmp_path, network):
     assert abs(l_gpu - l_cpu) <= 1e-5
 
 
+def test_syn_products_h2gcn2_logits(tmp_path):
+    """BASELINE.json configs[1]: syn-products-shaped graph (reference generator, n=10k, h=0.2), synthetic
+    class-conditional features d=100, `--no_feature_normalize` (experiments/h2gcn/configs/syn-products/h2gcn.json),
+    H2GCN-2 forward: r1, r2 (d=64 and d=128 launches) and logits within 1e-5 of the CPU oracle interpreter."""
+    from conftest import load_syn_products_golden
+    from h2gcn_amd import HopPlan, operands
+    from h2gcn_amd.models import parse_network_setup
+    from h2gcn_amd.models.H2GCN import H2GCN
+    from oracle import operands as oo
+
+    a, labels, _ = load_syn_products_golden()
+    rng = np.random.default_rng(5)
+    centers = rng.standard_normal((10, 100))
+    feats = (centers[labels] + rng.standard_normal((10000, 100))).astype(np.float32)
+    dev = torch.device("cuda:0")
+    hops = operands.build_adj_norm_hops(operands.remove_self_loops(a), ["1", "2"], "sym")
+    plan = HopPlan.from_scipy(hops, dev, build_transpose=True)
+    fplan = HopPlan.from_scipy([sp.csr_matrix(feats)], dev, build_transpose=True)
+    setup = parse_network_setup(H2GCN2, 10, _dense_units=64, _dropout_rate=0.5)
+    torch.manual_seed(1)
+    model = H2GCN(setup, input_dim=100, n_hops=2, l2_regularize_weight=5e-4).to(dev).eval()
+    tagged = {}
+    with torch.no_grad():
+        logits = model(None, fplan, plan, tagged_out=tagged)
+    weights = [l.kernel.detach().cpu().numpy() for l in model.regularized]
+    ohops = oo.adj_norm_hops(oo.remove_eye(a), ("1", "2"), oo.SYM)  # the oracle's own operand construction
+    want, want_tagged, trace = om.forward(_enc(setup), sp.csr_matrix(feats), ohops, weights, return_tagged=True)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(logits.cpu().numpy() - want).max() <= 1e-5 * scale
+    assert np.abs(tagged["2"].cpu().numpy() - want_tagged["2"]).max() <= 1e-5 * max(1.0, np.abs(want_tagged["2"]).max())
+    assert plan.nnz == [h.nnz for h in ohops]
+
+
 def test_gradients_match_dense_float64_replica(tmp_path):
     g, data, tensors, setup, model = _setup(tmp_path)
     model.eval()  # no dropout: deterministic comparison

@@ -105,3 +105,18 @@ def test_rows_subset_matches_full():
     sub = og.rows_subset([oo.to_canonical_csr(m) for m in hops], x, rows)
     full = og.gcn_layer_f64acc(hops, x)
     np.testing.assert_allclose(sub, full[rows], atol=1e-12)
+
+
+def test_oracle_reproduces_stored_layer_outputs():
+    """tests/golden/cora_layer_outputs.npz (scipy csr @ dense, made by make_golden.py): the C oracle gives the
+    same fp32 rows bit-for-bit and the same column sums."""
+    from conftest import GOLDEN
+    z = np.load(GOLDEN / "cora_layer_outputs.npz")
+    g = load_planetoid_golden("cora")
+    hops = [g["hop1_sym"], g["hop2_sym"]]
+    x = np.random.Generator(np.random.PCG64(123)).uniform(-1, 1, (g["n"], 64)).astype(np.float32)
+    r1 = og.gcn_layer_c(hops, x).reshape(g["n"], 128)
+    r2 = og.gcn_layer_c(hops, r1).reshape(g["n"], 256)
+    assert np.array_equal(r1[z["rows"]], z["r1_rows"]) and np.array_equal(r2[z["rows"]], z["r2_rows"])
+    assert np.abs(r1.astype(np.float64).sum(0) - z["r1_colsum64"]).max() < 1e-4
+    assert np.abs(r2.astype(np.float64).sum(0) - z["r2_colsum64"]).max() < 1e-4

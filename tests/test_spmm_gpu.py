@@ -91,6 +91,23 @@ def test_cora_two_stacked_layers_r1_r2():
     assert np.abs(r2.cpu().numpy() - w2).max() <= ATOL
 
 
+def test_cora_stored_layer_outputs():
+    """HIP r1 / r2 against the STORED golden rows and fp64 column sums (tests/golden/cora_layer_outputs.npz)."""
+    from conftest import GOLDEN
+    from h2gcn_amd import GCNLayer, HopPlan
+
+    z = np.load(GOLDEN / "cora_layer_outputs.npz")
+    g = load_planetoid_golden("cora")
+    plan = HopPlan.from_scipy([g["hop1_sym"], g["hop2_sym"]], dev())
+    x = np.random.Generator(np.random.PCG64(123)).uniform(-1, 1, (g["n"], 64)).astype(np.float32)
+    r1 = GCNLayer()(plan, torch.from_numpy(x).to(dev())).flatten(1)
+    r2 = GCNLayer()(plan, r1).flatten(1)
+    assert np.abs(r1.cpu().numpy()[z["rows"]] - z["r1_rows"]).max() <= ATOL
+    assert np.abs(r2.cpu().numpy()[z["rows"]] - z["r2_rows"]).max() <= ATOL
+    assert np.abs(r1.double().sum(0).cpu().numpy() - z["r1_colsum64"]).max() <= 1e-4
+    assert np.abs(r2.double().sum(0).cpu().numpy() - z["r2_colsum64"]).max() <= 1e-4
+
+
 @pytest.mark.parametrize("d", [64, 128])
 def test_syn_products_fixture(d):
     """BASELINE.json configs[1]: syn-products h=0.2, |V|=10k -- graph from the reference generator, exact 2-hop
