@@ -37,6 +37,8 @@ def add_subparser_args(parser):
     g.add_argument("--adj_norm", choices=["sym", "rw"], default="sym",
                    help="hop normalisation: sym = D^-1/2 A D^-1/2 (reference default), rw = D^-1 A")
     g.add_argument("--device", type=str, default="cuda:0", dest="_device")
+    g.add_argument("--no_hipgraph", action="store_true", dest="_no_hipgraph",
+                   help="run every step eagerly instead of replaying captured hipGraphs")
     parser.function_hooks["argparse"].append(argparse_callback)
 
 
@@ -62,10 +64,10 @@ def preprocessing_data(args, adj_norm_hops=None):
                                                   norm=args.adj_norm)
 
 
-def make_optimizer(name: str, params, lr: float):
+def make_optimizer(name: str, params, lr: float, capturable: bool = False):
     name = name.lower()
     if name == "adam":  # keras defaults: beta 0.9 / 0.999, epsilon 1e-7
-        return torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=1e-7)
+        return torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=1e-7, capturable=capturable)
     if name == "sgd":
         return torch.optim.SGD(params, lr=lr)
     if name == "rmsprop":
@@ -78,7 +80,8 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
     device = torch.device(args._device)
     model = H2GCN(layer_setups, input_dim=tensors["features"].n_cols, n_hops=(tensors["adj_hops"].n_hops
                   if tensors["adj_hops"] is not None else 0), l2_regularize_weight=l2_regularize_weight).to(device)
-    optimizer = make_optimizer(optimizer, model.parameters(), lr)
+    use_graphs = not getattr(args, "_no_hipgraph", False) and optimizer.lower() == "adam"
+    optimizer = make_optimizer(optimizer, model.parameters(), lr, capturable=use_graphs)
     snapshot = logger.BestSnapshot()
 
     def train_step(adj, adj_hops, features, y_train, train_mask, **kwargs):
@@ -113,13 +116,20 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
         model.eval()
         return model.get_embeddings(adj, features, adj_hops)
 
+    if use_graphs:
+        train_step, test_step = _GraphedSteps(train_step, test_step, optimizer, device).wrap()
+
     stats_printer = logger.EpochStatsPrinter()
     args.objects["statsPrinter"] = stats_printer
     args.objects["best_val_stats"] = None
     args.objects["early_stopping"] = controller.SlidingMeanEarlyStopping(early_stopping)
 
     def post_epoch_callback(epoch, args):
-        stats = {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in args.objects["epoch_stats"].items()}
+        raw = args.objects["epoch_stats"]
+        names = [k for k, v in raw.items() if isinstance(v, torch.Tensor)]
+        values = torch.stack([raw[k].detach().float().reshape(()) for k in names]).tolist()  # ONE device->host sync
+        stats = dict(raw)
+        stats.update(zip(names, values))
         args.objects["epoch_stats"] = stats
         stats_printer(epoch, stats)
         if args.objects["early_stopping"](stats["val_loss"]):
@@ -144,6 +154,66 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
                         test_step=test_step, predict_step=predict_step, embed_step=embed_step)
     args.objects["post_epoch_callbacks"].append(post_epoch_callback)
     args.objects["post_train_callbacks"].append(post_train_callback)
+
+
+class _GraphedSteps:
+    """Full-batch training is the same launch sequence every epoch (static adjacency, static shapes), and on small
+    graphs (Cora: ~90 short kernels per epoch) it is launch-bound.  After ``WARMUP`` eager epochs -- which also
+    populate the plan's per-hop-mask caches, the only allocations the HIP library ever makes -- the train step and
+    the test step are each captured into a hipGraph (``torch.cuda.CUDAGraph``; the C-ABI launches go to the
+    capturing stream like any other kernel) and replayed.  Outputs are static tensors; the eager closures remain
+    the fallback if capture fails."""
+
+    WARMUP = 3
+
+    def __init__(self, train_step, test_step, optimizer, device):
+        self.eager_train, self.eager_test = train_step, test_step
+        self.optimizer, self.device = optimizer, device
+        self.calls = 0
+        self.train_graph = self.test_graph = None
+        self.train_out = self.test_out = None
+        self.failed = False
+
+    def _capture(self, tensors):
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):  # one more eager pass on a side stream, as torch's capture recipe asks;
+            eager_out = self.eager_train(**tensors)  # it is also this epoch's real update
+            self.eager_test(**tensors)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self.optimizer.zero_grad(set_to_none=True)
+        g_train = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_train):
+            train_out = self.eager_train(**tensors)
+        g_test = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_test):
+            test_out = self.eager_test(**tensors)
+        self.train_graph, self.test_graph, self.train_out, self.test_out = g_train, g_test, train_out, test_out
+        return eager_out
+
+    def wrap(self):
+        def train_step(**tensors):
+            self.calls += 1
+            if self.failed or self.calls <= self.WARMUP:
+                return self.eager_train(**tensors)
+            if self.train_graph is None:
+                try:
+                    return self._capture(tensors)  # capture records, the eager pass inside it did the update
+                except Exception as e:  # pragma: no cover - depends on the runtime
+                    print(f"hipGraph capture unavailable ({type(e).__name__}: {e}); continuing eagerly")
+                    self.failed, self.train_graph, self.test_graph = True, None, None
+                    torch.cuda.synchronize()
+                    return self.eager_train(**tensors)
+            self.train_graph.replay()
+            return dict(self.train_out)
+
+        def test_step(**tensors):
+            if self.failed or self.test_graph is None:
+                return self.eager_test(**tensors)
+            self.test_graph.replay()
+            return dict(self.test_out)
+
+        return train_step, test_step
 
 
 class Dense(torch.nn.Module):

@@ -400,3 +400,70 @@ def test_baseline_shapes_properties(shape):
         want = og.rows_subset(local, xs, list(range(8)))
         got = y[r0:r0 + 8].cpu().numpy()
         assert np.abs(got - want).max() <= ATOL
+
+
+# ----------------------------------------------------------------------------- maximum sizes: 64-bit offsets
+def test_x_beyond_4gib_uses_64bit_gather_offsets():
+    """X of 4.6 GB: byte offsets into the gather source exceed 32 bits, so the launch takes the 64-bit-offset
+    kernels (the reference needs a column split at nnz*d > 2^31 on GPU, `_layers.py:65-74`; here nothing splits)."""
+    from h2gcn_amd import HopPlan
+
+    device = dev()
+    n_cols, d, n_rows = 9_000_000, 128, 4096
+    assert n_cols * d * 4 > 2 ** 32
+    base = torch.arange(n_cols, device=device, dtype=torch.float32).remainder_(1000.0).mul_(1e-3)
+    x = (base[:, None] + torch.arange(d, device=device, dtype=torch.float32)[None, :] * 1e-2).contiguous()
+    rng = np.random.default_rng(4)
+    deg = rng.integers(0, 40, n_rows)
+    deg[7] = 700  # one long segment too
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    cols = np.concatenate([np.sort(rng.choice(n_cols, k, replace=False)) for k in deg]).astype(np.int32)
+    cols[-1] = n_cols - 1 if deg[-1] > 0 else cols[-1]  # touch the very last row of X
+    vals = rng.uniform(-1, 1, len(cols)).astype(np.float32)
+    m = sp.csr_matrix((vals, cols, rowptr), shape=(n_rows, n_cols))
+    m.sort_indices()
+    plan = HopPlan.from_scipy([m, m[::-1]], device)
+    y = plan.spmm(x).cpu().numpy()
+    # oracle on the referenced rows of X only
+    used = np.unique(m.indices)
+    xs = x[torch.from_numpy(used.astype(np.int64)).to(device)].cpu().numpy()
+    remap = sp.csr_matrix((m.data, np.searchsorted(used, m.indices), m.indptr), shape=(n_rows, len(used)))
+    want = og.gcn_layer_f64acc([remap, remap[::-1]], xs)
+    mag = og.gcn_layer_f64acc([abs(remap), abs(remap[::-1])], np.abs(xs))
+    assert (np.abs(y - want) <= ATOL * np.maximum(1.0, mag)).all()
+
+
+def test_more_than_2_31_nonzeros():
+    """2.3e9 nonzeros in one hop matrix: row pointers beyond int32 -- the size the reference's GPU path cannot
+    index.  Operands are built by formula on the device (18 GB); checks: row-stochastic property on every row,
+    and sampled rows (first, last, across the 2^31 boundary) against the fp64 oracle."""
+    from h2gcn_amd import HopPlan
+
+    device = dev()
+    n_rows, deg, n_cols, d = 36_000, 64_000, 100_000, 32
+    nnz = n_rows * deg
+    assert nnz > 2 ** 31
+    rowptr = torch.arange(n_rows + 1, device=device, dtype=torch.int64) * deg
+    # row i holds columns (i * 7 + t * stride_i) mod n_cols for t < deg, made ascending by construction:
+    # start_i + t  (a contiguous window, wrapped rows avoided by clamping the start)
+    start = (torch.arange(n_rows, device=device, dtype=torch.int64) * 7919) % (n_cols - deg)
+    colidx = torch.empty(nnz, dtype=torch.int32, device=device)
+    step = 4000
+    ar = torch.arange(deg, device=device, dtype=torch.int32)
+    for r0 in range(0, n_rows, step):
+        r1 = min(r0 + step, n_rows)
+        colidx[r0 * deg:r1 * deg] = (start[r0:r1, None].to(torch.int32) + ar[None, :]).reshape(-1)
+    vals = torch.full((nnz,), 1.0 / deg, dtype=torch.float32, device=device)
+    plan = HopPlan([rowptr], [colidx], [vals], n_cols)
+    assert plan.info(0)["nnz"] == nnz and plan.info(0)["n_long_segments"] == n_rows
+    ones = torch.ones((n_cols, d), device=device)
+    y1 = plan.spmm(ones)
+    assert (y1 - 1).abs().max().item() <= 1e-4
+    x = torch.rand((n_cols, d), device=device) * 2 - 1
+    y = plan.spmm(x)[:, 0]
+    csum = torch.cat([torch.zeros((1, d), dtype=torch.float64, device=device), x.double().cumsum(0)])
+    boundary = (2 ** 31) // deg
+    for i in (0, 1, boundary - 1, boundary, boundary + 1, n_rows - 1):
+        s = int(start[i])
+        want = (csum[s + deg] - csum[s]) / deg   # mean of a contiguous window of X rows, in fp64
+        assert (y[i].double() - want).abs().max().item() <= ATOL
