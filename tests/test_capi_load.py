@@ -68,3 +68,12 @@ def test_product_never_imports_the_oracle():
     for p in (ROOT / "h2gcn_amd" / "csrc").glob("*"):
         if p.suffix in (".hip", ".h", ".cpp"):
             assert "oracle" not in p.read_text().lower(), f"{p} mentions the oracle"
+
+
+def test_header_is_plain_c_and_library_links_without_python(tmp_path):
+    """tools/capi_demo.c compiles as C99 with gcc against include/h2gcn_hip.h and links libh2gcn_hip.so alone
+    (it is executed by the GPU suite)."""
+    import __graft_entry__ as ge
+
+    exe = ge.build_capi_demo()
+    assert exe.exists()
