@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--shape", default="products", choices=["products", "arxiv"])
+    ap.add_argument("--shape", default="products", choices=["products", "arxiv", "lowdeg"])
     ap.add_argument("--d", type=int, default=0, help="feature width (default: the shape's, 128)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--long-row-threshold", type=int, default=0)
@@ -215,7 +215,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[{3 if a.shape == 'products' else 2}]"
+            "workload": ({"products": "BASELINE configs[3]", "arxiv": "BASELINE configs[2]"}.get(a.shape, f"(not a BASELINE config) {a.shape}"))
                         + (f"/configs[4] row-partitioned over {world} GPUs" if world > 1 else "")
                         + f": synthetic CSR |V|={n}, nnz(A1)={nnz_global[0]}, nnz(A2)={nnz_global[1]}, d={d}, "
                           "row-normalised values 1/deg, 2-hop CSR supplied (not derived)",

@@ -177,7 +177,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 // Column-slice width of the EXACT kernels: the largest fast width that divides d, capped so that the gather
 // working set of one slice (n_src_rows * slice * 4 B) is friendlier to the 256 MiB Infinity Cache when the whole
 // operand is far beyond it.  `forced` > 0 (plan option) overrides the heuristic.
-int pick_slice_cols(int d, int64_t n_src_rows, int forced) {
+int pick_slice_cols(int d, int64_t n_src_rows, int forced, double avg_segment_nnz) {
     static const int widths[] = {256, 128, 64, 32};
     if (forced > 0 && d % forced == 0) return forced;  // a forced width that does not divide d falls back to the heuristic
     int best = 0;
@@ -185,16 +185,20 @@ int pick_slice_cols(int d, int64_t n_src_rows, int forced) {
         if (d % w != 0) continue;
         if (best == 0) best = w;
         const double slice_bytes = (double)n_src_rows * w * 4.0;
-        if (w >= 64 && slice_bytes > 768.0 * 1024 * 1024 && d % (w / 2) == 0) continue;  // prefer a narrower slice
+        // narrower slices pay one more pass over the row pointers / indices and one more latency chain per
+        // segment: only worth it when segments are long enough to amortise that, and never below 64 columns
+        if (w > 64 && avg_segment_nnz >= 16.0 && slice_bytes > 768.0 * 1024 * 1024 && d % (w / 2) == 0) continue;
         return w;
     }
     return best;
 }
 
 template <bool SUM>
-int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_slice, int64_t n_src_rows, hipStream_t stream) {
+int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_slice, int64_t n_src_rows,
+           double avg_segment_nnz, hipStream_t stream) {
     using namespace h2gcn;
-    const int slice = (vec_ok && variant != 1) ? pick_slice_cols(p.d, n_src_rows, forced_slice) : 0;
+    const bool pipe = (variant != 3) && p.rows_per_wave * p.n_sel <= 32;  // variant 3 = plain walk; skip mask is 32 bits
+    const int slice = (vec_ok && variant != 1) ? pick_slice_cols(p.d, n_src_rows, forced_slice, avg_segment_nnz) : 0;
     const bool exact = slice > 0 || (vec_ok && variant == 1 && p.d == 128);
     p.slice_cols = exact ? (slice > 0 ? slice : 128) : p.d;
     p.n_slices = exact ? p.d / p.slice_cols : 1;
@@ -203,12 +207,16 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
     if (n_blocks <= 0) return H2GCN_OK;
     if (n_blocks > 0x7fffffffLL) return fail(H2GCN_ERR_INVALID_ARGUMENT, "grid too large (%lld blocks)", (long long)n_blocks);
     const dim3 grid((unsigned)n_blocks), block(kBlock);
-#define H2GCN_LAUNCH(VEC, LPR, EXACT)                                                                      \
-    do {                                                                                                   \
-        if (off32)                                                                                         \
-            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, true>), grid, block, 0, stream, p);  \
-        else                                                                                               \
-            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, false>), grid, block, 0, stream, p); \
+#define H2GCN_LAUNCH(VEC, LPR, EXACT)                                                                             \
+    do {                                                                                                          \
+        if (off32 && pipe && EXACT)                                                                               \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, true, true>), grid, block, 0, stream, p);   \
+        else if (off32)                                                                                           \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, true, false>), grid, block, 0, stream, p);  \
+        else if (pipe && EXACT)                                                                                   \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, false, true>), grid, block, 0, stream, p);  \
+        else                                                                                                      \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, false, false>), grid, block, 0, stream, p); \
     } while (0)
     if (exact && variant == 1 && slice == 0) {
         H2GCN_LAUNCH(2, 64, true);  // one neighbour per load instruction, scalar base addressing
@@ -423,10 +431,12 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
         LaunchParams p;
         memset(&p, 0, sizeof(p));
         int s = 0;
+        int64_t nnz_sel = 0;
         bool vec_ok = aligned16(X) && aligned16(Y) && ldx % 4 == 0 && ldy_row % 4 == 0;
         for (int k = 0; k < plan->n_hops; ++k) {
             if (!(mask & (1u << k))) continue;
             const HopOperand& op = plan->fwd[k];
+            nnz_sel += op.nnz;
             p.hop[s] = HopCsr{op.rowptr, op.colidx, op.vals};
             p.src_hop_off[s] = 0;
             p.dst_hop_off[s] = (int64_t)s * ldy_hop;
@@ -450,7 +460,8 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
         p.tiles_per_xcd = (p.n_tiles + h2gcn::kNumXcd - 1) / h2gcn::kNumXcd;
         // 32-bit gather offsets when the farthest byte of X is below 4 GiB
         const bool off32 = ((double)(plan->n_cols > 0 ? plan->n_cols - 1 : 0) * (double)ldx + d) * 4.0 < 4294967296.0;
-        return launch<false>(p, plan->variant, vec_ok, off32, plan->slice_cols, plan->n_cols, (hipStream_t)stream_v);
+        return launch<false>(p, plan->variant, vec_ok, off32, plan->slice_cols, plan->n_cols,
+                             (double)nnz_sel / ((double)p.n_rows * s), (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_f32");
     }
@@ -474,10 +485,12 @@ int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const flo
         LaunchParams p;
         memset(&p, 0, sizeof(p));
         int s = 0;
+        int64_t nnz_sel = 0;
         bool vec_ok = aligned16(dY) && aligned16(dX) && ldx % 4 == 0 && ldg_row % 4 == 0;
         for (int k = 0; k < plan->n_hops; ++k) {
             if (!(mask & (1u << k))) continue;
             const HopOperand& op = plan->adj[k];
+            nnz_sel += op.nnz;
             p.hop[s] = HopCsr{op.rowptr, op.colidx, op.vals};
             p.src_hop_off[s] = (int64_t)s * ldg_hop;
             p.dst_hop_off[s] = 0;
@@ -499,7 +512,8 @@ int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const flo
         p.n_tiles = (p.n_rows + rows_per_tile - 1) / rows_per_tile;
         p.tiles_per_xcd = (p.n_tiles + h2gcn::kNumXcd - 1) / h2gcn::kNumXcd;
         const bool off32 = ((double)(plan->n_rows > 0 ? plan->n_rows - 1 : 0) * (double)ldg_row + (double)(s - 1) * (double)ldg_hop + d) * 4.0 < 4294967296.0;
-        return launch<true>(p, plan->variant, vec_ok, off32, plan->slice_cols, plan->n_rows, (hipStream_t)stream_v);
+        return launch<true>(p, plan->variant, vec_ok, off32, plan->slice_cols, plan->n_rows,
+                            (double)nnz_sel / ((double)p.n_rows * s), (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_T_f32");
     }

@@ -198,6 +198,44 @@ __device__ __forceinline__ void gather_batch(int c, float v, int t, int g, const
     for (int u = 0; u < U; ++u) fma_vec<VEC>(acc, w[u], x[u]);
 }
 
+// (column id, value) of neighbour `lane` of the 64-wide chunk starting at `base` (zero beyond the segment end)
+__device__ __forceinline__ void load_chunk(const int32_t* __restrict__ colidx, const float* __restrict__ vals,
+                                           int64_t base, int64_t seg_end, int lane, int& c, float& v) {
+    c = 0;
+    v = 0.f;
+    if (base + lane < seg_end) {
+        c = __builtin_nontemporal_load(colidx + base + lane);
+        v = __builtin_nontemporal_load(vals + base + lane);
+    }
+}
+
+// All gathers + multiply-adds of one chunk of n (<= 64) neighbours held lane-wise in (c, v).
+template <int VEC, int LPR, bool MASKED, bool OFF32>
+__device__ __forceinline__ void process_chunk(int c, float v, int n, int g, const GatherAddr<OFF32>& addr,
+                                              bool lane_active, float (&acc)[VEC]) {
+    constexpr int G = kWave / LPR;
+    const int full = n / G;  // steps in which every lane group has a neighbour
+    int t = 0;
+    for (; t + 8 <= full; t += 8) gather_batch<VEC, LPR, 8, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
+    if (t + 4 <= full) {
+        gather_batch<VEC, LPR, 4, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
+        t += 4;
+    }
+    if (t + 2 <= full) {
+        gather_batch<VEC, LPR, 2, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
+        t += 2;
+    }
+    if (t + 1 <= full) {
+        gather_batch<VEC, LPR, 1, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
+        t += 1;
+    }
+    if constexpr (G > 1) {
+        // ragged last step: only the first (n - full*G) groups still have a neighbour
+        const int rem = n - full * G;
+        if (rem > 0) gather_batch<VEC, LPR, 1, true, OFF32>(c, v, full, g, addr, lane_active && g < rem, acc);
+    }
+}
+
 // Accumulate sum_j val_j * src[col_j, :] over the nonzeros [seg_begin, seg_end) of one CSR row, taking the
 // 64-wide chunks chunk0, chunk0+chunk_step, ... (regular path: all of them; long path: this wave's share).
 // Each lane group accumulates its neighbours in ascending order into acc.
@@ -207,37 +245,37 @@ __device__ __forceinline__ void accumulate_segment(const int32_t* __restrict__ c
                                                    int64_t seg_end, int chunk0, int chunk_step,
                                                    const GatherAddr<OFF32>& addr, int lane, bool lane_active,
                                                    float (&acc)[VEC]) {
-    constexpr int G = kWave / LPR;
     const int g = lane / LPR;
     for (int64_t base = seg_begin + (int64_t)chunk0 * kWave; base < seg_end; base += (int64_t)chunk_step * kWave) {
         const int64_t left = seg_end - base;
         const int n = left < kWave ? (int)left : kWave;
-        int c = 0;
-        float v = 0.f;
-        if (lane < n) {
-            c = __builtin_nontemporal_load(colidx + base + lane);
-            v = __builtin_nontemporal_load(vals + base + lane);
-        }
-        const int full = n / G;  // steps in which every lane group has a neighbour
-        int t = 0;
-        for (; t + 8 <= full; t += 8) gather_batch<VEC, LPR, 8, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
-        if (t + 4 <= full) {
-            gather_batch<VEC, LPR, 4, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
-            t += 4;
-        }
-        if (t + 2 <= full) {
-            gather_batch<VEC, LPR, 2, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
-            t += 2;
-        }
-        if (t + 1 <= full) {
-            gather_batch<VEC, LPR, 1, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
-            t += 1;
-        }
-        if constexpr (G > 1) {
-            // ragged last step: only the first (n - full*G) groups still have a neighbour
-            const int rem = n - full * G;
-            if (rem > 0) gather_batch<VEC, LPR, 1, true, OFF32>(c, v, full, g, addr, lane_active && g < rem, acc);
-        }
+        int c;
+        float v;
+        load_chunk(colidx, vals, base, seg_end, lane, c, v);
+        process_chunk<VEC, LPR, MASKED, OFF32>(c, v, n, g, addr, lane_active, acc);
+    }
+}
+
+// Same sum, software-pipelined: the first chunk (c, v) was fetched by the caller while the PREVIOUS segment was
+// still gathering, and every further chunk is fetched before the current one is processed -- the index fetch
+// latency leaves the per-segment dependency chain (index -> gather -> fold -> store), which is what bounds
+// short rows.  Loads retire in order, so waiting for the gathers implies the prefetch has landed.
+template <int VEC, int LPR, bool OFF32>
+__device__ __forceinline__ void accumulate_segment_prefetched(const int32_t* __restrict__ colidx,
+                                                              const float* __restrict__ vals, int64_t seg_begin,
+                                                              int64_t seg_end, int c, float v,
+                                                              const GatherAddr<OFF32>& addr, int lane,
+                                                              float (&acc)[VEC]) {
+    const int g = lane / LPR;
+    for (int64_t base = seg_begin; base < seg_end; base += kWave) {
+        const int64_t left = seg_end - base;
+        const int n = left < kWave ? (int)left : kWave;
+        int c_next = 0;
+        float v_next = 0.f;
+        if (left > kWave) load_chunk(colidx, vals, base + kWave, seg_end, lane, c_next, v_next);
+        process_chunk<VEC, LPR, false, OFF32>(c, v, n, g, addr, true, acc);
+        c = c_next;
+        v = v_next;
     }
 }
 
@@ -261,7 +299,7 @@ __device__ __forceinline__ void store_vec(float* p, const float (&acc)[VEC]) {
 //        and each wave loops over masked column tiles (any d)
 // SUM    adjoint mode: one output row = sum over the selected hops
 // OFF32  32-bit gather offsets (see GatherAddr)
-template <int VEC, int LPR, bool EXACT, bool SUM, bool OFF32>
+template <int VEC, int LPR, bool EXACT, bool SUM, bool OFF32, bool PIPE = false>
 __global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hops_kernel(const LaunchParams p) {
     static_assert(EXACT || LPR == kWave, "column-tiled path uses the whole wave per row");
     __shared__ float partial[kWavesPerBlock][kMaxTileCols];
@@ -340,6 +378,59 @@ __global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hop
     auto seg_bound = [&](int l) -> int64_t {
         return ((int64_t)__builtin_amdgcn_readlane(rp_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(rp_lo, l);
     };
+
+    if constexpr (PIPE && EXACT) {
+        // ---- software-pipelined walk over the wave's (row, hop) segments: prefetch the next segment's first
+        //      index chunk before gathering the current one ----
+        const int n_seg = rows_here * n_sel;
+        uint32_t skip = 0;  // bit q: segment q belongs to a workgroup of the long path
+        for (int q = 0; q < n_seg; ++q) {
+            const int r = q / n_sel, s_ = q - r * n_sel;
+            const int l0 = s_ * (rpw + 1) + r;
+            if (seg_bound(l0 + 1) - seg_bound(l0) >= p.long_threshold) skip |= SUM ? (((1u << n_sel) - 1u) << (r * n_sel)) : (1u << q);
+        }
+        auto seg = [&](int q, int& s_, int64_t& sb, int64_t& se) {
+            const int r = q / n_sel;
+            s_ = q - r * n_sel;
+            const int l0 = s_ * (rpw + 1) + r;
+            sb = seg_bound(l0);
+            se = (skip >> q) & 1u ? sb : seg_bound(l0 + 1);
+        };
+        int s_cur, s_nxt = 0;
+        int64_t b_cur, e_cur, b_nxt = 0, e_nxt = 0;
+        int c_cur, c_nxt = 0;
+        float v_cur, v_nxt = 0.f;
+        seg(0, s_nxt, b_nxt, e_nxt);
+        load_chunk(p.hop[s_nxt].colidx, p.hop[s_nxt].vals, b_nxt, e_nxt, lane, c_nxt, v_nxt);
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        for (int q = 0; q < n_seg; ++q) {
+            s_cur = s_nxt; b_cur = b_nxt; e_cur = e_nxt; c_cur = c_nxt; v_cur = v_nxt;
+            if (q + 1 < n_seg) {
+                seg(q + 1, s_nxt, b_nxt, e_nxt);
+                load_chunk(p.hop[s_nxt].colidx, p.hop[s_nxt].vals, b_nxt, e_nxt, lane, c_nxt, v_nxt);
+            }
+            const int r = q / n_sel;
+            const int64_t row = row0 + r;
+            const HopCsr& h = p.hop[s_cur];
+            const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s_cur] + col_begin),
+                                         (off_t)(li * VEC * 4), (off_t)(p.ld_src * 4)};
+            accumulate_segment_prefetched<VEC, LPR, OFF32>(h.colidx, h.vals, b_cur, e_cur, c_cur, v_cur, addr, lane, acc);
+            const bool skipped = (skip >> q) & 1u;
+            if (!SUM || s_cur == n_sel - 1) {
+                if (!skipped) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
+                    if (g == 0)
+                        store_vec<VEC>(p.dst + row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_cur]) + col_begin + li * VEC, acc);
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            }
+        }
+        return;
+    }
 
     for (int r = 0; r < rows_here; ++r) {
         const int64_t row = row0 + r;

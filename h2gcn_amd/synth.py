@@ -146,5 +146,7 @@ def synth_features(d: int, seed: int, r0: int, r1: int, device) -> torch.Tensor:
 SHAPES = {
     "arxiv": dict(n=170_000, nnz_per_hop=1_200_000, d=128),       # configs[2]
     "products": dict(n=2_400_000, nnz_per_hop=120_000_000, d=128),  # configs[3], configs[4]
+    # not a BASELINE config: a low-degree stress shape (mean degree ~4, like Cora's 1-hop) for the short-row path
+    "lowdeg": dict(n=8_000_000, nnz_per_hop=32_000_000, d=128),
 }
 SEED_A1, SEED_A2, SEED_X = 123, 124, 125
