@@ -64,8 +64,9 @@ typedef struct h2gcn_plan_opts {
     int32_t long_row_threshold;  /* (row,hop) segments with >= this many nonzeros are split across the
                                     waves of one workgroup (LDS-staged partial sums); default 256          */
     int32_t rows_per_wave;       /* consecutive rows a wave walks in the regular path; default 4           */
-    int32_t variant;             /* kernel variant: 0 = default (index prefetch across segments); 1 = scalar-
-                                    addressed float2 gathers at d=128; 3 = plain (un-pipelined) segment walk  */
+    int32_t variant;             /* kernel variant: 0 = default (index prefetch across segments when segments
+                                    average < 16 nonzeros); 1 = scalar-addressed float2 gathers at d=128;
+                                    2 = always prefetch; 3 = never prefetch                                   */
     int32_t slice_cols;          /* feature columns per slice of the slice-major schedule: 32/64/128/256,
                                     0 = heuristic (narrower slices when X is far beyond the Infinity Cache)  */
     int32_t reserved[2];

@@ -198,16 +198,16 @@ def test_column_slices_do_not_change_results(d):
 
 @pytest.mark.parametrize("d", [64, 128, 256])
 def test_variant_pipelined_segment_walk_is_bitwise_identical(d):
-    """The default segment walk prefetches the next segment's index chunk while the current one gathers; variant=3
-    is the plain walk.  Prefetching only re-times loads: same arithmetic, same bits -- forward and adjoint, with
-    long segments and empty rows in the mix."""
+    """variant=2 prefetches the next segment's index chunk while the current one gathers (the default does so on
+    short-segment operands), variant=3 is the plain walk.  Prefetching only re-times loads: same arithmetic, same
+    bits -- forward and adjoint, with long segments and empty rows in the mix."""
     from h2gcn_amd import HopPlan
 
     hops = [rand_csr(1200, 900, 0.02, 1, empty_frac=0.2), rand_csr(1200, 900, 0.15, 2, empty_frac=0.05)]
     hops[0] = sp.csr_matrix(sp.vstack([hops[0][:9], sp.csr_matrix(np.full((1, 900), 0.02, dtype=np.float32)), hops[0][10:]]))
     x = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (900, d)).astype(np.float32)).to(dev())
     w = torch.from_numpy(np.random.default_rng(2).uniform(-1, 1, (1200, 2, d)).astype(np.float32)).to(dev())
-    ref = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=128)
+    ref = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=128, variant=2)
     for rpw in (0, 1, 7):
         alt = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=128, variant=3, rows_per_wave=rpw)
         assert torch.equal(ref.spmm(x), alt.spmm(x))
