@@ -394,6 +394,16 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
             }
             plan->has_transpose = true;
         }
+        // build the long-segment lists of the common selection (all hops) now, so that launches with the default
+        // hop mask never allocate -- they can be issued inside a hipGraph capture without a warm-up
+        {
+            const uint32_t all = n_hops >= 32 ? 0xffffffffu : ((1u << n_hops) - 1u);
+            const int64_t* unused_p = nullptr;
+            int unused_n = 0;
+            int st = get_long_list(plan.get(), false, all, &unused_p, &unused_n);
+            if (st == H2GCN_OK && plan->has_transpose) st = get_long_list(plan.get(), true, all, &unused_p, &unused_n);
+            if (st != H2GCN_OK) return st;
+        }
         *out_plan = plan.release();
         return H2GCN_OK;
     } catch (const std::bad_alloc&) {

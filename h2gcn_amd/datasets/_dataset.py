@@ -125,7 +125,7 @@ class PlanetoidData:
 
     # ------------------------------------------------------------------ tensors
     def get_tensors(self, device, adj_norm_hops: Optional[Sequence[str]] = None, norm: str = operands.SYM_NORMALIZED,
-                    build_transpose: bool = True) -> dict:
+                    build_transpose: bool = True, host_hops: bool = False) -> dict:
         """``adj`` / ``features`` / ``adj_hops`` as device operands + dense label/mask tensors (keys as the
         reference's ``tensors`` namespace: ``H2GCN.py:66,77-79``)."""
         import torch
@@ -135,9 +135,12 @@ class PlanetoidData:
         t = {}
         t["features"] = HopPlan.from_scipy([self.features], device, build_transpose=build_transpose)
         t["adj"] = HopPlan.from_scipy([self.sparse_adj], device)
-        if adj_norm_hops:
+        if adj_norm_hops and host_hops:      # scipy SpGEMM on the host, as the reference does
             hops = operands.build_adj_norm_hops(self.sparse_adj, adj_norm_hops, norm)
             t["adj_hops"] = HopPlan.from_scipy(hops, device, build_transpose=build_transpose)
+        elif adj_norm_hops:                  # exact-k-hop rings grown on the GPU (bit-identical operands)
+            rp, ci, va, n = operands.build_adj_norm_hops_device(self.sparse_adj, adj_norm_hops, norm, device)
+            t["adj_hops"] = HopPlan(rp, ci, va, n, build_transpose=build_transpose)
         else:
             t["adj_hops"] = None
         for name in ("y_all", "y_train", "y_val", "y_test"):

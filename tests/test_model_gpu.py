@@ -97,6 +97,34 @@ def test_syn_products_h2gcn2_logits(tmp_path):
     assert plan.nnz == [h.nnz for h in ohops]
 
 
+def test_device_built_hops_equal_host_built(tmp_path):
+    """get_tensors grows the exact-k-hop rings on the GPU by default; the operands equal the scipy-built ones bit
+    for bit (so does a forward pass), on Cora and on the 10k-node syn-products graph (2.8M-nonzero 2-hop ring)."""
+    from conftest import load_syn_products_golden
+    from h2gcn_amd import HopPlan, operands
+    from h2gcn_amd.datasets._dataset import PlanetoidData
+
+    _cora_files(tmp_path)
+    data = PlanetoidData("ind.cora", tmp_path, val_size=500)
+    data.adj_remove_eye()
+    dev = torch.device("cuda:0")
+    td = data.get_tensors(dev, adj_norm_hops=["1", "2"])
+    th = data.get_tensors(dev, adj_norm_hops=["1", "2"], host_hops=True)
+    for k in range(2):
+        assert torch.equal(td["adj_hops"].rowptr[k], th["adj_hops"].rowptr[k])
+        assert torch.equal(td["adj_hops"].colidx[k], th["adj_hops"].colidx[k])
+        assert torch.equal(td["adj_hops"].vals[k], th["adj_hops"].vals[k])
+    a, _, _ = load_syn_products_golden()
+    adj = operands.remove_self_loops(a)
+    rp, ci, va, n = operands.build_adj_norm_hops_device(adj, ["1", "2"], "sym", dev)
+    host = operands.build_adj_norm_hops(adj, ["1", "2"], "sym")
+    for k, h in enumerate(host):
+        h = sp.csr_matrix(h); h.sort_indices()
+        assert np.array_equal(ci[k].cpu().numpy(), h.indices) and np.array_equal(va[k].cpu().numpy(), h.data.astype(np.float32))
+    x = torch.rand((n, 64), device=dev)
+    assert torch.equal(HopPlan(rp, ci, va, n).spmm(x), HopPlan.from_scipy(host, dev).spmm(x))
+
+
 def test_gradients_match_dense_float64_replica(tmp_path):
     g, data, tensors, setup, model = _setup(tmp_path)
     model.eval()  # no dropout: deterministic comparison
