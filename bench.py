@@ -134,11 +134,17 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: h2gcn_amd has no CPU fallback")
+    if os.environ.get("H2GCN_BENCH_SHARE_GPU") == "1":  # debugging aid: several ranks on one GPU (if RCCL allows it)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("H2GCN_DIST_BACKEND", "nccl")  # "gloo" only for the shared-GPU debugging mode
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from h2gcn_amd import HopPlan, synth
     from h2gcn_amd.partition import PipelinedHopAggregation, block_bounds

@@ -64,7 +64,7 @@ class EmbeddingAllGather:
         else:  # last (short) block: pad to the common count
             self.send[: self.r1 - self.r0].copy_(x_local)
             send = self.send
-        dist.all_gather_into_tensor(self.full, send, group=self.group)
+        _all_gather_rows(self.full, send, self.group)
         return self.full[: self.n_rows]
 
 
@@ -146,7 +146,7 @@ class PipelinedHopAggregation:
             self.send[c][:n_local].copy_(x_local[:, c * dc:(c + 1) * dc])
         if not self.use_streams:
             for c in range(self.C):
-                dist.all_gather_into_tensor(self.full[c], self.send[c], group=self.group)
+                _all_gather_rows(self.full[c], self.send[c], self.group)
                 self._spmm(self.full[c][: self.n], out[:, :, c * dc:(c + 1) * dc])
             return out
         main = torch.cuda.current_stream(self.device)
@@ -154,12 +154,22 @@ class PipelinedHopAggregation:
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self.staged)
             for c in range(self.C):
-                dist.all_gather_into_tensor(self.full[c], self.send[c], group=self.group)
+                _all_gather_rows(self.full[c], self.send[c], self.group)
                 self.ready[c].record(self.comm_stream)
         for c in range(self.C):
             main.wait_event(self.ready[c])
             self._spmm(self.full[c][: self.n], out[:, :, c * dc:(c + 1) * dc])
         return out
+
+
+def _all_gather_rows(full: torch.Tensor, send: torch.Tensor, group=None) -> None:
+    """``full`` ([P*per, d]) <- concatenation of every rank's ``send`` ([per, d]).  RCCL: one ``ncclAllGather``.
+    gloo has no flat all-gather for device tensors, so the list form is used there (CPU tests, and the
+    shared-GPU debugging mode of the GPU suite)."""
+    if dist.get_backend(group) == "gloo" and full.is_cuda:
+        dist.all_gather(list(full.chunk(dist.get_world_size(group), dim=0)), send, group=group)
+    else:
+        dist.all_gather_into_tensor(full, send, group=group)
 
 
 def _reduce_scatter_rows(full: torch.Tensor, per: int, rank: int, group=None) -> torch.Tensor:
