@@ -129,7 +129,11 @@ __device__ __forceinline__ float fold_groups(float v) {
 
 template <int VEC>
 __device__ __forceinline__ typename VecT<VEC>::type load_vec(const float* p) {
+#ifdef H2GCN_NT_GATHER
+    return __builtin_nontemporal_load(reinterpret_cast<const typename VecT<VEC>::type*>(p));
+#else
     return *reinterpret_cast<const typename VecT<VEC>::type*>(p);
+#endif
 }
 
 template <int VEC>
