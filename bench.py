@@ -134,7 +134,7 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: h2gcn_amd has no CPU fallback")
-    if os.environ.get("H2GCN_BENCH_SHARE_GPU") == "1":  # debugging aid: several ranks on one GPU (if RCCL allows it)
+    if os.environ.get("H2GCN_SHARE_GPU") == "1":  # debugging aid: several ranks on one GPU (if RCCL allows it)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)

@@ -125,13 +125,18 @@ class PlanetoidData:
 
     # ------------------------------------------------------------------ tensors
     def get_tensors(self, device, adj_norm_hops: Optional[Sequence[str]] = None, norm: str = operands.SYM_NORMALIZED,
-                    build_transpose: bool = True, host_hops: bool = False) -> dict:
+                    build_transpose: bool = True, host_hops: bool = False, shard=None) -> dict:
         """``adj`` / ``features`` / ``adj_hops`` as device operands + dense label/mask tensors (keys as the
-        reference's ``tensors`` namespace: ``H2GCN.py:66,77-79``)."""
+        reference's ``tensors`` namespace: ``H2GCN.py:66,77-79``).
+
+        ``shard = (rank, world)``: row-partitioned run -- this rank gets rows ``[r0, r1)`` of the features, of every
+        hop matrix (as :class:`~h2gcn_amd.partition.ShardedHops`) and of the labels/masks."""
         import torch
 
         from ..hops import HopPlan
 
+        if shard is not None:
+            return self._get_tensors_sharded(device, adj_norm_hops, norm, shard)
         t = {}
         t["features"] = HopPlan.from_scipy([self.features], device, build_transpose=build_transpose)
         t["adj"] = HopPlan.from_scipy([self.sparse_adj], device)
@@ -149,6 +154,35 @@ class PlanetoidData:
             t[name] = torch.from_numpy(getattr(self, name)).to(device)
         t["labels"] = torch.from_numpy(self.labels).to(device)
         return t
+
+
+def _sharded_tensors(self, device, adj_norm_hops, norm, shard):
+    import torch
+
+    from ..hops import HopPlan
+    from ..partition import ShardedHops, block_bounds, slice_csr_rows
+
+    rank, world = shard
+    n = self.num_samples
+    r0, r1 = block_bounds(n, world, rank)
+    t = {"adj": None}
+    t["features"] = HopPlan.from_scipy([sp.csr_matrix(self.features)[r0:r1]], device, build_transpose=True)
+    if adj_norm_hops:
+        rp, ci, va, _ = operands.build_adj_norm_hops_device(self.sparse_adj, adj_norm_hops, norm, device)
+        parts = [slice_csr_rows(rp[k], ci[k], va[k], r0, r1) for k in range(len(rp))]
+        plan = HopPlan([p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts], n, build_transpose=True)
+        t["adj_hops"] = ShardedHops(plan, n, device)
+    else:
+        t["adj_hops"] = None
+    for name in ("y_all", "y_train", "y_val", "y_test"):
+        t[name] = torch.from_numpy(np.asarray(getattr(self, name), dtype=np.float32)[r0:r1]).to(device)
+    for name in ("train_mask", "val_mask", "test_mask"):
+        t[name] = torch.from_numpy(getattr(self, name)[r0:r1]).to(device)
+    t["labels"] = torch.from_numpy(self.labels[r0:r1]).to(device)
+    return t
+
+
+PlanetoidData._get_tensors_sharded = _sharded_tensors
 
 
 def export_planetoid(path, name, adj, features, labels_onehot, n_train: int, test_ids: Sequence[int],

@@ -58,6 +58,8 @@ class GCNLayer(torch.nn.Module):
 
     def forward(self, adjhops: HopPlan, inputs: torch.Tensor) -> torch.Tensor:
         sel = None
+        if hasattr(adjhops, "aggregate"):  # partition.ShardedHops: all-gather + local SpMM (+ reduce-scatter backward)
+            return adjhops.aggregate(inputs, None if self.hops is None else sorted(self.hops))
         if self.hops is not None:
             sel = [h for h in range(adjhops.n_hops) if h in self.hops]
             if not sel:

@@ -13,6 +13,7 @@ from __future__ import annotations
 import operator
 
 import torch
+import torch.distributed as dist
 
 from .. import layers as L
 from ..modules import controller, logger
@@ -60,8 +61,13 @@ def preprocessing_data(args, adj_norm_hops=None):
     if not args.no_feature_normalize:
         dataset.row_normalize_features()
     dataset.adj_remove_eye()
+    shard = (dist.get_rank(), dist.get_world_size()) if _is_sharded() else None
     args.objects["tensors"] = dataset.get_tensors(torch.device(args._device), adj_norm_hops=adj_norm_hops,
-                                                  norm=args.adj_norm)
+                                                  norm=args.adj_norm, shard=shard)
+
+
+def _is_sharded() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def make_optimizer(name: str, params, lr: float, capturable: bool = False):
@@ -80,7 +86,8 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
     device = torch.device(args._device)
     model = H2GCN(layer_setups, input_dim=tensors["features"].n_cols, n_hops=(tensors["adj_hops"].n_hops
                   if tensors["adj_hops"] is not None else 0), l2_regularize_weight=l2_regularize_weight).to(device)
-    use_graphs = not getattr(args, "_no_hipgraph", False) and optimizer.lower() == "adam"
+    sharded = _is_sharded()
+    use_graphs = not getattr(args, "_no_hipgraph", False) and optimizer.lower() == "adam" and not sharded
     optimizer = make_optimizer(optimizer, model.parameters(), lr, capturable=use_graphs)
     snapshot = logger.BestSnapshot()
 
@@ -116,6 +123,8 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
         model.eval()
         return model.get_embeddings(adj, features, adj_hops)
 
+    if sharded:
+        train_step, test_step = _sharded_steps(model, optimizer)
     if use_graphs:
         train_step, test_step = _GraphedSteps(train_step, test_step, optimizer, device).wrap()
 
@@ -131,7 +140,8 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
         stats = dict(raw)
         stats.update(zip(names, values))
         args.objects["epoch_stats"] = stats
-        stats_printer(epoch, stats)
+        if not _is_sharded() or dist.get_rank() == 0:
+            stats_printer(epoch, stats)
         if args.objects["early_stopping"](stats["val_loss"]):
             print("Early stopping...")
             args.epochs = epoch
@@ -142,18 +152,75 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
             snapshot.save(model, optimizer)
 
     def post_train_callback(args):
-        print("Restoring the best performance model")
         snapshot.restore(model, optimizer)
         stats = args.objects["test_step"](**args.objects["tensors"])
         args.objects["best_val_stats"]["monitor"] = stats["monitor"]
-        print("Best performance:")
-        stats_printer.from_dict(args.objects["best_val_stats"])
+        if not _is_sharded() or dist.get_rank() == 0:
+            print("Restoring the best performance model")
+            print("Best performance:")
+            stats_printer.from_dict(args.objects["best_val_stats"])
         snapshot.write(getattr(args, "checkpoint_dir", None))
 
     args.objects.update(model=model, optimizer=optimizer, checkpoint=snapshot, train_step=train_step,
                         test_step=test_step, predict_step=predict_step, embed_step=embed_step)
     args.objects["post_epoch_callbacks"].append(post_epoch_callback)
     args.objects["post_train_callbacks"].append(post_train_callback)
+
+
+def _sharded_steps(model, optimizer):
+    """Step closures of a row-partitioned run (one process per GPU).  Every rank holds the rows ``[r0, r1)`` of the
+    features / hop matrices / labels and a full replica of the (small) dense kernels:
+
+    * forward: ``SparseDense`` and everything after the propagation are row-local; each ``G`` layer all-gathers the
+      embedding over RCCL (feature-chunk pipelined) and aggregates its row block;
+    * loss: ``sum_local(CE_i * mask_i) / sum_global(mask)`` + ``L2 / world`` per rank, so that the SUM over ranks is
+      the reference's loss (masked mean + L2, ``H2GCN.py:363-367``);
+    * backward: each ``G`` layer's adjoint yields a full-height contribution that is reduce-scattered to the row
+      owners (``partition.sharded_hop_spmm``); kernel gradients are summed over ranks (all-reduce), then every
+      rank applies the same Adam update -- replicas stay bit-identical."""
+    world = dist.get_world_size()
+
+    def global_sum(x):
+        x = x.detach().clone()
+        dist.all_reduce(x)
+        return x
+
+    def partial_ce(preds, labels, mask):
+        m = mask.to(torch.float32)
+        ce = -(labels * torch.log_softmax(preds, dim=1)).sum(dim=1)
+        return (ce * m).sum() / global_sum(m.sum())
+
+    def partial_acc(preds, labels, mask):
+        m = mask.to(torch.float32)
+        correct = (preds.argmax(dim=1) == labels.argmax(dim=1)).to(torch.float32)
+        return (correct * m).sum() / global_sum(m.sum())
+
+    def train_step(adj, adj_hops, features, y_train, train_mask, **kwargs):
+        model.train()
+        optimizer.zero_grad(set_to_none=True)
+        predictions = model(adj, features, adj_hops)
+        ce = partial_ce(predictions, y_train, train_mask)
+        reg = model.regularization_loss()
+        (ce + reg / world).backward()
+        for p in model.parameters():
+            if p.grad is not None:
+                dist.all_reduce(p.grad)
+        optimizer.step()
+        return dict(train_loss=global_sum(ce) + reg.detach())
+
+    @torch.no_grad()
+    def test_step(adj, adj_hops, features, y_train, train_mask, y_val, val_mask, y_test, test_mask, **kwargs):
+        model.eval()
+        predictions = model(adj, features, adj_hops)
+        reg = model.regularization_loss()
+        parts = torch.stack([partial_acc(predictions, y_train, train_mask), partial_acc(predictions, y_val, val_mask),
+                             partial_acc(predictions, y_test, test_mask), partial_ce(predictions, y_val, val_mask),
+                             partial_ce(predictions, y_test, test_mask)])
+        dist.all_reduce(parts)
+        return dict(train_acc=parts[0], val_acc=parts[1], test_accuracy=parts[2], val_loss=parts[3] + reg,
+                    test_loss=parts[4], monitor=dict())
+
+    return train_step, test_step
 
 
 class _GraphedSteps:

@@ -211,3 +211,40 @@ def sharded_hop_spmm(layer: "PipelinedHopAggregation", x_local: torch.Tensor) ->
     if x_local.requires_grad and torch.is_grad_enabled():
         return _ShardedHopSpMM.apply(x_local, layer)
     return layer(x_local)
+
+
+class ShardedHops:
+    """One rank's view of ``adj_hops`` in a row-partitioned run: the local row block ``A_k[rows_p, :]`` of every hop
+    matrix (a rectangular :class:`~h2gcn_amd.hops.HopPlan`, global column ids, transposed operands for the
+    backward) plus the per-width exchange pipelines.  ``GCNLayer`` accepts it in place of a ``HopPlan``:
+    ``layer(sharded_hops, x_local) -> [n_local, H, d]`` all-gathers ``x_local`` (feature-chunk pipelined) and
+    aggregates; its backward is the shard adjoint followed by a reduce-scatter."""
+
+    def __init__(self, plan, n_global: int, device, group: Optional[dist.ProcessGroup] = None, chunk_cols: int = 32,
+                 max_chunks: int = 4):
+        self.plan = plan
+        self.n_global = int(n_global)
+        self.device = device
+        self.group = group
+        self.chunk_cols, self.max_chunks = int(chunk_cols), int(max_chunks)
+        self.n_hops, self.n_rows, self.n_cols = plan.n_hops, plan.n_rows, plan.n_cols
+        self._pipes = {}
+
+    def pipeline(self, d: int) -> "PipelinedHopAggregation":
+        if d not in self._pipes:
+            chunks = 1
+            while chunks * 2 <= self.max_chunks and d % (chunks * 2) == 0 and d // (chunks * 2) >= self.chunk_cols:
+                chunks *= 2
+            self._pipes[d] = PipelinedHopAggregation(self.plan, self.n_global, d, chunks, self.device, self.group)
+        return self._pipes[d]
+
+    def aggregate(self, x_local: torch.Tensor, hops=None) -> torch.Tensor:
+        if hops is not None:
+            raise NotImplementedError("hop filters (G0, G0_1, ...) are not supported in row-partitioned runs yet")
+        return sharded_hop_spmm(self.pipeline(int(x_local.shape[1])), x_local)
+
+
+def slice_csr_rows(rowptr: torch.Tensor, colidx: torch.Tensor, vals: torch.Tensor, r0: int, r1: int):
+    """Rows [r0, r1) of a device CSR (global column ids kept)."""
+    lo, hi = int(rowptr[r0]), int(rowptr[r1])
+    return (rowptr[r0:r1 + 1] - lo).contiguous(), colidx[lo:hi].contiguous(), vals[lo:hi].contiguous()

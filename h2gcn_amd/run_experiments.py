@@ -7,9 +7,11 @@ the callbacks.  Example (planetoid files of Cora in ./data):
 
     python -m h2gcn_amd.run_experiments H2GCN planetoid --dataset ind.cora --dataset_path data --epochs 200
 """
+import os
 import time
 
 import torch
+import torch.distributed as dist
 
 from . import datasets, models
 from .modules import arguments, logger
@@ -23,11 +25,33 @@ def build_parser():
     return parser
 
 
+def init_distributed():
+    """One process per GPU when launched by ``python -m torch.distributed.run`` (WORLD_SIZE > 1): RCCL process
+    group, rank r on GPU LOCAL_RANK, ``--device`` defaulted accordingly.  ``H2GCN_DIST_BACKEND=gloo`` with
+    ``H2GCN_SHARE_GPU=1`` is the debugging mode the GPU test-suite uses to run two ranks on a one-GPU box."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or (dist.is_available() and dist.is_initialized()):
+        return
+    local = 0 if os.environ.get("H2GCN_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    backend = os.environ.get("H2GCN_DIST_BACKEND", "nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    import sys
+
+    if not any(a.startswith("--device") for a in sys.argv):
+        sys.argv += ["--device", f"cuda:{local}"]
+
+
 def main(argv=None):
     import sys
 
     if argv is not None:  # plugin discovery peeks at sys.argv through parse_known_args
         sys.argv = [sys.argv[0]] + list(argv)
+    init_distributed()
     parser = build_parser()
     known, _ = parser.parse_known_args()
     if known.random_seed:

@@ -81,3 +81,50 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, chunks):
     dx2 = np.concatenate([np.load(tmp_path / f"dx{r}.npy") for r in range(2)], 0)
     assert np.array_equal(y2, y.cpu().numpy())                     # forward: bit-for-bit
     assert np.abs(dx2 - dx.cpu().numpy()).max() <= 1e-5            # adjoint: the cross-rank sum re-associates
+
+
+TRAIN_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["H2GCN_ROOT"])
+from h2gcn_amd import run_experiments
+args = run_experiments.main(["H2GCN", "planetoid", "--dataset", "ind.cora", "--dataset_path", os.environ["DATA_DIR"],
+                             "--epochs", "12", "--random_seed", "11", "--network_setup", "M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO"])
+if int(os.environ.get("RANK", "0")) == 0:
+    stats = {k: float(v) for k, v in args.objects["epoch_stats"].items() if k != "monitor"}
+    json.dump(stats, open(os.environ["OUT_FILE"], "w"))
+'''
+
+
+def test_row_partitioned_training_matches_single_process(tmp_path):
+    """`run_experiments` under torch.distributed (2 ranks, rows of features / hop matrices / labels partitioned,
+    dense kernels replicated, all-gather forward, reduce-scatter + gradient all-reduce backward) follows the
+    single-process training trajectory.  Dropout is disabled so both runs are deterministic."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import load_planetoid_golden
+    from test_entrypoints import _export_fixture
+
+    data_dir = tmp_path / "data"
+    _export_fixture(load_planetoid_golden("cora"), data_dir, "ind.cora")
+    results = {}
+    for world in (1, 2):
+        port = _free_port()
+        procs = []
+        out_file = tmp_path / f"stats{world}.json"
+        for rank in range(world):
+            env = dict(os.environ, H2GCN_ROOT=str(ROOT), DATA_DIR=str(data_dir), OUT_FILE=str(out_file))
+            if world > 1:
+                env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                           MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1")
+            else:
+                env.pop("WORLD_SIZE", None)
+            procs.append(subprocess.Popen([sys.executable, "-c", TRAIN_WORKER], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        results[world] = json.loads(out_file.read_text())
+        if world == 2:
+            assert "Epoch: 0012" in outs[0] and "Epoch: 0012" not in outs[1]  # only rank 0 prints
+    a, b = results[1], results[2]
+    assert a["train_loss"] < 1.9
+    for k in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_accuracy"):
+        assert abs(a[k] - b[k]) <= 2e-3, (k, a[k], b[k])
