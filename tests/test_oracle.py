@@ -120,3 +120,18 @@ def test_oracle_reproduces_stored_layer_outputs():
     assert np.array_equal(r1[z["rows"]], z["r1_rows"]) and np.array_equal(r2[z["rows"]], z["r2_rows"])
     assert np.abs(r1.astype(np.float64).sum(0) - z["r1_colsum64"]).max() < 1e-4
     assert np.abs(r2.astype(np.float64).sum(0) - z["r2_colsum64"]).max() < 1e-4
+
+
+def test_oracle_agrees_with_an_independent_implementation():
+    """Third implementation as a cross-check of the restatement: torch's CPU sparse-CSR matmul (different code
+    base, different loop structure) agrees with the C oracle to fp32 rounding on the Cora operands."""
+    import torch
+
+    g = load_planetoid_golden("cora")
+    x = np.random.Generator(np.random.PCG64(5)).uniform(-1, 1, (g["n"], 32)).astype(np.float32)
+    for name in ("hop1_sym", "hop2_rw"):
+        m = g[name]
+        t = torch.sparse_csr_tensor(torch.from_numpy(m.indptr.astype(np.int64)), torch.from_numpy(m.indices.astype(np.int64)),
+                                    torch.from_numpy(m.data.astype(np.float32)), size=m.shape)
+        got = (t @ torch.from_numpy(x)).numpy()
+        assert np.abs(got - og.gcn_layer_c([m], x)[:, 0, :]).max() <= 2e-6
