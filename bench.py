@@ -119,7 +119,8 @@ def main():
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--slice-cols", type=int, default=0, help="feature columns per slice (0 = library heuristic)")
     ap.add_argument("--chunks", type=int, default=-1,
-                    help="feature chunks of the pipelined all-gather/SpMM (default: 1 on one GPU, 4 on several)")
+                    help="feature chunks of the pipelined all-gather/SpMM (default: 1 on one GPU; on several, the "
+                         "fastest of 1/2/4 as timed during warm-up)")
     ap.add_argument("--adjoint", action="store_true", help="also time the backward (adjoint) launch; extra, not the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -160,8 +161,6 @@ def main():
                    variant=a.variant, long_row_threshold=a.long_row_threshold, rows_per_wave=a.rows_per_wave,
                    slice_cols=a.slice_cols, build_transpose=a.adjoint)
     x_local = synth.synth_features(d, synth.SEED_X, r0, r1, device)
-    chunks = a.chunks if a.chunks > 0 else (1 if world == 1 else 4)
-    layer = PipelinedHopAggregation(plan, n, d, chunks, device)
     y = torch.empty((r1 - r0, 2, d), dtype=torch.float32, device=device)
     nnz_local = plan.nnz
     nnz_t = torch.tensor(nnz_local, dtype=torch.int64, device=device)
@@ -169,25 +168,60 @@ def main():
         dist.all_reduce(nnz_t)
     nnz_global = [int(v) for v in nnz_t.tolist()]
 
-    fallback = None
-    try:
-        for _ in range(max(a.warmup, 1)):
-            layer(x_local, out=y)
-        torch.cuda.synchronize()
-    except Exception as e:  # keep a number even if the pipelined exchange is unavailable on this node
-        if world == 1 or chunks == 1:
-            raise
-        fallback = f"{type(e).__name__}: {e}"
-        chunks = 1
-        layer = PipelinedHopAggregation(plan, n, d, 1, device)
-        for _ in range(max(a.warmup, 1)):
-            layer(x_local, out=y)
-    layer.kernel_events = []   # HIP events around every SpMM launch, on the stream it is launched on
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed_ms(fn, reps):
+        """max over ranks of the mean wall time of `fn` (barrier + device sync on both sides)."""
+        barrier()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        v = torch.tensor([(time.perf_counter() - t) / reps * 1e3], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v.item())
+
+    # Exchange schedule.  On one GPU: a single fused launch.  On several: the all-gather is pipelined against the
+    # SpMM in feature chunks; how many chunks pay off depends on the node's RCCL/xGMI rates, so (unless --chunks is
+    # given) the candidates are timed during warm-up and the fastest is used for the measured steps.  The
+    # calibration numbers and the comm-only / compute-only times are reported as diagnostics.
+    fallback, diagnostics = None, {}
+    if a.chunks > 0 or world == 1:
+        chunks = a.chunks if a.chunks > 0 else 1
+        layer = PipelinedHopAggregation(plan, n, d, chunks, device)
+    else:
+        cands = {}
+        for c in (1, 2, 4):
+            if d % c or d // c < 32:
+                continue
+            try:
+                cand = PipelinedHopAggregation(plan, n, d, c, device)
+                for _ in range(2):
+                    cand(x_local, out=y)
+                cands[c] = (timed_ms(lambda: cand(x_local, out=y), 3), cand)
+            except Exception as e:  # keep a number even if one schedule is unavailable on this node
+                fallback = f"chunks={c}: {type(e).__name__}: {e}"
+        if not cands:
+            raise SystemExit(f"no exchange schedule works: {fallback}")
+        chunks = min(cands, key=lambda c: cands[c][0])
+        layer = cands[chunks][1]
+        diagnostics["calibration_ms_per_step"] = {str(c): v[0] for c, v in cands.items()}
+        # comm-only and compute-only times of the chosen chunking (not part of the metric)
+        from h2gcn_amd.partition import _all_gather_rows
+        if chunks >= 1 and hasattr(layer, "full"):
+            diagnostics["allgather_only_ms"] = timed_ms(
+                lambda: [_all_gather_rows(layer.full[c], layer.send[c]) for c in range(layer.C)], 3)
+            diagnostics["spmm_only_ms"] = timed_ms(
+                lambda: [plan.spmm(layer.full[c][:n], out=y[:, :, c * layer.dc:(c + 1) * layer.dc]) for c in range(layer.C)], 3)
+        del cands
+    for _ in range(max(a.warmup, 1)):
+        layer(x_local, out=y)
+    torch.cuda.synchronize()
+    layer.kernel_events = []   # HIP events around every SpMM launch, on the stream it is launched on
 
     barrier()
     t0 = time.perf_counter()
@@ -227,7 +261,8 @@ def main():
                           "row-normalised values 1/deg, 2-hop CSR supplied (not derived)",
             "n_rows": n, "nnz_per_hop": nnz_global, "d": d,
             "parallelism": f"row-partition x{world}" + (", RCCL all-gather of X per step" if world > 1 else ""),
-            "kernel_variant": a.variant, "feature_chunks": chunks, "pipeline_fallback": fallback, "slice_cols": a.slice_cols or "auto",
+            "kernel_variant": a.variant, "feature_chunks": chunks, "pipeline_fallback": fallback,
+            "diagnostics": diagnostics, "slice_cols": a.slice_cols or "auto",
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
