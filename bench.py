@@ -195,26 +195,33 @@ def main():
         layer = PipelinedHopAggregation(plan, n, d, chunks, device)
     else:
         cands = {}
-        for c in (1, 2, 4):
-            if d % c or d // c < 32:
-                continue
-            try:
-                cand = PipelinedHopAggregation(plan, n, d, c, device)
-                for _ in range(2):
-                    cand(x_local, out=y)
-                cands[c] = (timed_ms(lambda: cand(x_local, out=y), 3), cand)
-            except Exception as e:  # keep a number even if one schedule is unavailable on this node
-                fallback = f"chunks={c}: {type(e).__name__}: {e}"
+        for exchange in ("allgather", "p2p"):       # one ncclAllGather vs P-1 grouped ncclSend/ncclRecv per rank
+            for c in (1, 2, 4):
+                if d % c or d // c < 32:
+                    continue
+                ok = torch.ones(1, device=device)
+                try:
+                    cand = PipelinedHopAggregation(plan, n, d, c, device, exchange=exchange)
+                    for _ in range(2):
+                        cand(x_local, out=y)
+                    torch.cuda.synchronize()
+                except Exception as e:  # a schedule that is unavailable on this node is simply not a candidate
+                    fallback = f"{exchange} chunks={c}: {type(e).__name__}: {e}"
+                    ok.zero_()
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank must agree before timing it
+                if ok.item() > 0:
+                    cands[(exchange, c)] = (timed_ms(lambda: cand(x_local, out=y), 3), cand)
         if not cands:
             raise SystemExit(f"no exchange schedule works: {fallback}")
-        chunks = min(cands, key=lambda c: cands[c][0])
-        layer = cands[chunks][1]
-        diagnostics["calibration_ms_per_step"] = {str(c): v[0] for c, v in cands.items()}
+        best = min(cands, key=lambda k: cands[k][0])
+        exchange, chunks = best
+        layer = cands[best][1]
+        diagnostics["exchange"] = exchange
+        diagnostics["calibration_ms_per_step"] = {f"{e}/{c}": v[0] for (e, c), v in cands.items()}
         # comm-only and compute-only times of the chosen chunking (not part of the metric)
-        from h2gcn_amd.partition import _all_gather_rows
         if chunks >= 1 and hasattr(layer, "full"):
-            diagnostics["allgather_only_ms"] = timed_ms(
-                lambda: [_all_gather_rows(layer.full[c], layer.send[c]) for c in range(layer.C)], 3)
+            diagnostics["exchange_only_ms"] = timed_ms(
+                lambda: [layer._gather(layer.full[c], layer.send[c], None) for c in range(layer.C)], 3)
             diagnostics["spmm_only_ms"] = timed_ms(
                 lambda: [plan.spmm(layer.full[c][:n], out=y[:, :, c * layer.dc:(c + 1) * layer.dc]) for c in range(layer.C)], 3)
         del cands

@@ -94,7 +94,11 @@ class PipelinedHopAggregation:
     FAST_WIDTHS = (32, 64, 128, 256)
 
     def __init__(self, plan, n_rows_global: int, d: int, n_chunks: int, device,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, exchange: str = "allgather"):
+        if exchange not in ("allgather", "p2p"):
+            raise ValueError(f"unknown exchange {exchange!r}")
+        self._gather = _all_gather_rows if exchange == "allgather" else _all_gather_rows_p2p
+        self.exchange = exchange
         if d % n_chunks != 0:
             raise ValueError(f"d = {d} is not divisible into {n_chunks} chunks")
         self.plan = plan
@@ -146,7 +150,7 @@ class PipelinedHopAggregation:
             self.send[c][:n_local].copy_(x_local[:, c * dc:(c + 1) * dc])
         if not self.use_streams:
             for c in range(self.C):
-                _all_gather_rows(self.full[c], self.send[c], self.group)
+                self._gather(self.full[c], self.send[c], self.group)
                 self._spmm(self.full[c][: self.n], out[:, :, c * dc:(c + 1) * dc])
             return out
         main = torch.cuda.current_stream(self.device)
@@ -154,7 +158,7 @@ class PipelinedHopAggregation:
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self.staged)
             for c in range(self.C):
-                _all_gather_rows(self.full[c], self.send[c], self.group)
+                self._gather(self.full[c], self.send[c], self.group)
                 self.ready[c].record(self.comm_stream)
         for c in range(self.C):
             main.wait_event(self.ready[c])
@@ -170,6 +174,24 @@ def _all_gather_rows(full: torch.Tensor, send: torch.Tensor, group=None) -> None
         dist.all_gather(list(full.chunk(dist.get_world_size(group), dim=0)), send, group=group)
     else:
         dist.all_gather_into_tensor(full, send, group=group)
+
+
+def _all_gather_rows_p2p(full: torch.Tensor, send: torch.Tensor, group=None) -> None:
+    """Same result as :func:`_all_gather_rows`, expressed as P-1 concurrent point-to-point transfers per rank
+    (``ncclSend``/``ncclRecv`` grouped): on a fully connected xGMI node every pair has its own link, so the direct
+    form keeps all 7 links busy instead of forwarding shards around a ring.  Which form is faster is a property of
+    the node/RCCL build; ``bench.py`` times both during warm-up."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = send.shape[0]
+    full[rank * per:(rank + 1) * per].copy_(send)
+    ops = []
+    for shift in range(1, world):
+        dst = (rank + shift) % world
+        src = (rank - shift) % world
+        ops.append(dist.P2POp(dist.isend, send, dst, group))
+        ops.append(dist.P2POp(dist.irecv, full[src * per:(src + 1) * per], src, group))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
 
 
 def _reduce_scatter_rows(full: torch.Tensor, per: int, rank: int, group=None) -> torch.Tensor:

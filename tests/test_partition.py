@@ -77,10 +77,11 @@ def _worker(rank, world, port, n, d, out_dir):
                 return torch.from_numpy(og.gcn_layer_grad_c(shard, grad.numpy(), n))
 
         for chunks in (1, 2, 4):
-            layer = PipelinedHopAggregation(OraclePlan, n, d, chunks, "cpu")
-            y_pipe = layer(x_local)
-            assert y_pipe.shape == (r1 - r0, 2, d)
-            assert np.array_equal(y_pipe.numpy(), y_local), chunks
+            for exchange in ("allgather", "p2p"):
+                layer = PipelinedHopAggregation(OraclePlan, n, d, chunks, "cpu", exchange=exchange)
+                y_pipe = layer(x_local)
+                assert y_pipe.shape == (r1 - r0, 2, d)
+                assert np.array_equal(y_pipe.numpy(), y_local), (chunks, exchange)
 
         # distributed backward: adjoint on the shard + reduce-scatter == rows [r0, r1) of the global adjoint
         from h2gcn_amd.partition import sharded_hop_spmm
