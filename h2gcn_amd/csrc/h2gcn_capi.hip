@@ -66,6 +66,8 @@ struct HopOperand {  // one CSR, device pointers
 struct LongList {
     DeviceBuf dev;
     int n = 0;
+    LongList() = default;
+    LongList(LongList&&) noexcept = default;
 };
 
 }  // namespace
@@ -159,13 +161,13 @@ int get_long_list(const h2gcn_plan* plan, bool adjoint, uint32_t mask, const int
             std::sort(host.begin(), host.end());
             host.erase(std::unique(host.begin(), host.end()), host.end());
         }
-        LongList& ll = plan->long_cache[key];
-        ll.n = (int)host.size();
-        if (ll.n > 0) {
-            H2GCN_HIP_TRY(hipMalloc(&ll.dev.p, host.size() * sizeof(int64_t)));
-            H2GCN_HIP_TRY(hipMemcpy(ll.dev.p, host.data(), host.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        LongList fresh;  // inserted into the cache only once it is complete
+        fresh.n = (int)host.size();
+        if (fresh.n > 0) {
+            H2GCN_HIP_TRY(hipMalloc(&fresh.dev.p, host.size() * sizeof(int64_t)));
+            H2GCN_HIP_TRY(hipMemcpy(fresh.dev.p, host.data(), host.size() * sizeof(int64_t), hipMemcpyHostToDevice));
         }
-        it = plan->long_cache.find(key);
+        it = plan->long_cache.emplace(key, std::move(fresh)).first;
     }
     *dev_out = (const int64_t*)it->second.dev.p;
     *n_out = it->second.n;
@@ -200,8 +202,9 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
     // index prefetch across segments: pays on short segments (+4 % at mean degree 4), costs ~0.4 % on long ones;
     // variant 2 forces it, variant 3 forbids it (bitwise-identical results either way)
     const bool pipe = (variant == 2 || (variant == 0 && avg_segment_nnz < 16.0)) && p.rows_per_wave * p.n_sel <= 32;
-    const int slice = (vec_ok && variant != 1) ? pick_slice_cols(p.d, n_src_rows, forced_slice, avg_segment_nnz) : 0;
-    const bool exact = slice > 0 || (vec_ok && variant == 1 && p.d == 128);
+    const bool scalar128 = vec_ok && variant == 1 && p.d == 128;  // variant 1 only exists for d = 128
+    const int slice = (vec_ok && !scalar128) ? pick_slice_cols(p.d, n_src_rows, forced_slice, avg_segment_nnz) : 0;
+    const bool exact = slice > 0 || scalar128;
     p.slice_cols = exact ? (slice > 0 ? slice : 128) : p.d;
     p.n_slices = exact ? p.d / p.slice_cols : 1;
     p.blocks_per_slice = (int64_t)p.n_long + p.tiles_per_xcd * kNumXcd;
@@ -220,7 +223,7 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
         else                                                                                                      \
             hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, false, false>), grid, block, 0, stream, p); \
     } while (0)
-    if (exact && variant == 1 && slice == 0) {
+    if (scalar128) {
         H2GCN_LAUNCH(2, 64, true);  // one neighbour per load instruction, scalar base addressing
     } else if (slice == 256) {
         H2GCN_LAUNCH(4, 64, true);
@@ -237,6 +240,14 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
     }
 #undef H2GCN_LAUNCH
     H2GCN_HIP_TRY(hipGetLastError());
+    return H2GCN_OK;
+}
+
+int check_device(const h2gcn_plan* plan) {
+    int cur = -1;
+    H2GCN_HIP_TRY(hipGetDevice(&cur));
+    if (cur != plan->device)
+        return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan lives on device %d but the current HIP device is %d", plan->device, cur);
     return H2GCN_OK;
 }
 
@@ -434,6 +445,7 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
         uint32_t mask;
         int st = resolve_mask(plan, hop_mask, &mask);
         if (st != H2GCN_OK) return st;
+        if ((st = check_device(plan)) != H2GCN_OK) return st;
         if (d < 1) return fail(H2GCN_ERR_INVALID_ARGUMENT, "d = %d", d);
         if (plan->n_rows == 0) return H2GCN_OK;
         if (!Y) return fail(H2GCN_ERR_INVALID_ARGUMENT, "Y is NULL");
@@ -488,6 +500,7 @@ int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const flo
         uint32_t mask;
         int st = resolve_mask(plan, hop_mask, &mask);
         if (st != H2GCN_OK) return st;
+        if ((st = check_device(plan)) != H2GCN_OK) return st;
         if (d < 1) return fail(H2GCN_ERR_INVALID_ARGUMENT, "d = %d", d);
         if (plan->n_cols == 0) return H2GCN_OK;
         if (!dX) return fail(H2GCN_ERR_INVALID_ARGUMENT, "dX is NULL");
