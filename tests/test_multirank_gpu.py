@@ -88,7 +88,7 @@ import json, os, sys
 sys.path.insert(0, os.environ["H2GCN_ROOT"])
 from h2gcn_amd import run_experiments
 args = run_experiments.main(["H2GCN", "planetoid", "--dataset", "ind.cora", "--dataset_path", os.environ["DATA_DIR"],
-                             "--epochs", "12", "--random_seed", "11", "--network_setup", "M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO"])
+                             "--epochs", "6", "--random_seed", "11", "--network_setup", "M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO"])
 if int(os.environ.get("RANK", "0")) == 0:
     stats = {k: float(v) for k, v in args.objects["epoch_stats"].items() if k != "monitor"}
     json.dump(stats, open(os.environ["OUT_FILE"], "w"))
@@ -123,8 +123,8 @@ def test_row_partitioned_training_matches_single_process(tmp_path):
         assert all(p.returncode == 0 for p in procs), "\n".join(outs)
         results[world] = json.loads(out_file.read_text())
         if world == 2:
-            assert "Epoch: 0012" in outs[0] and "Epoch: 0012" not in outs[1]  # only rank 0 prints
+            assert "Epoch: 0006" in outs[0] and "Epoch: 0006" not in outs[1]  # only rank 0 prints
     a, b = results[1], results[2]
-    assert a["train_loss"] < 1.9
+    assert a["train_loss"] < 1.95
     for k in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_accuracy"):
         assert abs(a[k] - b[k]) <= 2e-3, (k, a[k], b[k])
