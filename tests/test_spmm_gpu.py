@@ -367,6 +367,30 @@ def test_bitwise_repeatable_and_row_partition_invariant():
         assert np.array_equal(np.concatenate(parts, 0), full)
 
 
+def test_soak_repeated_launches_are_bitwise_stable():
+    """200 back-to-back launches (forward and adjoint, many long segments, concurrent streams) give the same bits
+    every time: no race in the LDS-staged long path, no dependence on scheduling."""
+    from h2gcn_amd import HopPlan, synth
+
+    device = dev()
+    n = 60_000
+    degs = [synth.synth_degrees(n, 30 * n, s, n) for s in (5, 6)]
+    csr = [synth.synth_hop_rows(degs[k], n, (5, 6)[k], 0, n, device) for k in range(2)]
+    plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n, build_transpose=True,
+                   long_row_threshold=48)
+    assert plan.info(0)["n_long_segments"] > 1000
+    x = synth.synth_features(128, 7, 0, n, device)
+    w = synth.synth_features(256, 8, 0, n, device).view(n, 2, 128)
+    y0, g0 = plan.spmm(x).clone(), plan.spmm_t(w).clone()
+    side = torch.cuda.Stream()
+    for i in range(100):
+        y = plan.spmm(x)
+        with torch.cuda.stream(side):   # same plan, another stream, at the same time
+            g = plan.spmm_t(w)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(y, y0) and torch.equal(g, g0), i
+
+
 # ----------------------------------------------------------------------------- error behaviour
 def test_errors_are_python_exceptions_before_or_at_the_c_call():
     from h2gcn_amd import HopPlan, _capi
