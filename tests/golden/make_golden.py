@@ -164,6 +164,10 @@ def dsl_fixture():
         "I-T1-G-V-C1-M64-R-D0.5-MO",           # experimental variant used in configs
         "F64-R-E-D-FO",                        # bias layers, embedding modifier, default dropout
         "M-R-T1-G0-V-T2-G0_1-V-C1_2-S1_0_32-D-MO",  # hop filters, multi-tag concat, slice
+        # every --network_setup that appears in experiments/h2gcn/configs/**/h2gcn.json and mlp.json
+        "M64-R-T1-G-V-T2-G-V-C1-C2-MO", "M64-R-T1-G-V-C1-MO", "M64-T1-G-V-T2-G-V-C1-C2-MO",
+        "M64-T1-G-V-T2-G-V-C1-C2-D0.5-MO", "M64-T1-G-V-C1-MO", "M64-T1-G-V-C1-D0.5-MO", "M64-R-D-MO", "M64-R-MO",
+        "M64-MO", "M64-D-MO",
     ]
 
     def enc(v):

@@ -17,7 +17,7 @@ def _enc(v):
 
 def test_matches_reference_parser():
     golden = json.loads((GOLDEN / "dsl_parse.json").read_text())
-    assert len(golden) == 6
+    assert len(golden) == 16
     for text, want in golden.items():
         got = parse_network_setup(text, 7, _dense_units=64, _dropout_rate=0.5, parse_preprocessing=True)
         assert [[t, {k: _enc(v) for k, v in c.items()}] for t, c in got] == want, text

@@ -42,7 +42,8 @@ def _enc(setup):
     return [[k, {kk: ({"__set__": sorted(v)} if isinstance(v, set) else v) for kk, v in c.items()}] for k, c in setup]
 
 
-@pytest.mark.parametrize("network", [H2GCN2, "M64-R-T1-G-V-C1-D0.5-MO", "M-R-T1-G0-V-T2-G0_1-V-C1_2-S1_0_32-D-MO"])
+@pytest.mark.parametrize("network", [H2GCN2, "M64-R-T1-G-V-C1-D0.5-MO", "M-R-T1-G0-V-T2-G0_1-V-C1_2-S1_0_32-D-MO",
+                                     "M64-T1-G-V-T2-G-V-C1-C2-MO", "M64-T1-G-V-C1-D0.5-MO", "M64-R-D-MO", "M64-MO"])
 def test_forward_matches_oracle_interpreter(tmp_path, network):
     g, data, tensors, setup, model = _setup(tmp_path, network)
     model.eval()
