@@ -1,5 +1,7 @@
 """GPU suite: property-based sweep (hypothesis) over operand shapes and every schedule knob -- forward and adjoint
 against the fp64 oracle, with the tolerance of tests/test_spmm_gpu.py."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -26,7 +28,7 @@ def _csr(rng, n_rows, n_cols, mean_deg, heavy, empty_frac):
     return m
 
 
-@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=int(os.environ.get("H2GCN_FUZZ_EXAMPLES", "150")), deadline=None, suppress_health_check=[HealthCheck.too_slow])
 @given(seed=st.integers(0, 2 ** 31 - 1), n_rows=st.integers(1, 700), n_cols=st.integers(1, 700),
        d=st.sampled_from([1, 2, 5, 8, 16, 32, 48, 64, 96, 128, 160, 256, 320]), n_hops=st.integers(1, 3),
        mean_deg=st.sampled_from([0.3, 3.0, 20.0, 70.0]), heavy=st.booleans(),
