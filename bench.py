@@ -196,12 +196,15 @@ def main():
     else:
         cands = {}
         for exchange in ("allgather", "p2p"):       # one ncclAllGather vs P-1 grouped ncclSend/ncclRecv per rank
-            for c in (1, 2, 4):
-                if d % c or d // c < 32:
+            for c in (1, 2, 4, "32+32+64"):
+                if isinstance(c, int) and (d % c or d // c < 32):
                     continue
+                if isinstance(c, str) and d != 128:
+                    continue
+                widths = c if isinstance(c, int) else [int(w) for w in c.split("+")]
                 ok = torch.ones(1, device=device)
                 try:
-                    cand = PipelinedHopAggregation(plan, n, d, c, device, exchange=exchange)
+                    cand = PipelinedHopAggregation(plan, n, d, widths, device, exchange=exchange)
                     for _ in range(2):
                         cand(x_local, out=y)
                     torch.cuda.synchronize()
@@ -219,11 +222,12 @@ def main():
         diagnostics["exchange"] = exchange
         diagnostics["calibration_ms_per_step"] = {f"{e}/{c}": v[0] for (e, c), v in cands.items()}
         # comm-only and compute-only times of the chosen chunking (not part of the metric)
-        if chunks >= 1 and hasattr(layer, "full"):
+        if hasattr(layer, "full"):
             diagnostics["exchange_only_ms"] = timed_ms(
                 lambda: [layer._gather(layer.full[c], layer.send[c], None) for c in range(layer.C)], 3)
             diagnostics["spmm_only_ms"] = timed_ms(
-                lambda: [plan.spmm(layer.full[c][:n], out=y[:, :, c * layer.dc:(c + 1) * layer.dc]) for c in range(layer.C)], 3)
+                lambda: [plan.spmm(layer.full[c][:n], out=y[:, :, layer.offsets[c]:layer.offsets[c] + layer.widths[c]])
+                         for c in range(layer.C)], 3)
         del cands
     for _ in range(max(a.warmup, 1)):
         layer(x_local, out=y)
@@ -275,7 +279,8 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": pmc_traffic(a.shape, d, chunks, a.slice_cols, world),
-            "kernel": "h2gcn::spmm_hops_kernel (fused 1+2-hop)" + (f", {chunks} launches of d/{chunks} columns" if chunks > 1 else ""),
+            "kernel": "h2gcn::spmm_hops_kernel (fused 1+2-hop)"
+                      + (f", {layer.C} launches over column chunks {layer.widths}" if layer.C > 1 else ""),
             "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_max,
             "algorithmic_bytes_per_launch": b_alg,
             "compulsory_bytes_per_launch": compulsory_bytes(nnz_local, r1 - r0, n, d, 2),

@@ -93,20 +93,30 @@ class PipelinedHopAggregation:
 
     FAST_WIDTHS = (32, 64, 128, 256)
 
-    def __init__(self, plan, n_rows_global: int, d: int, n_chunks: int, device,
+    def __init__(self, plan, n_rows_global: int, d: int, n_chunks, device,
                  group: Optional[dist.ProcessGroup] = None, exchange: str = "allgather"):
+        """``n_chunks``: number of equal feature chunks, or an explicit list of chunk widths summing to ``d``
+        (e.g. ``[32, 32, 64]``: a narrow first chunk shortens the un-overlapped head of the exchange, wider later
+        chunks keep the SpMM efficient)."""
         if exchange not in ("allgather", "p2p"):
             raise ValueError(f"unknown exchange {exchange!r}")
         self._gather = _all_gather_rows if exchange == "allgather" else _all_gather_rows_p2p
         self.exchange = exchange
-        if d % n_chunks != 0:
-            raise ValueError(f"d = {d} is not divisible into {n_chunks} chunks")
+        if isinstance(n_chunks, (list, tuple)):
+            widths = [int(w) for w in n_chunks]
+            if sum(widths) != d or min(widths) < 1:
+                raise ValueError(f"chunk widths {widths} do not sum to d = {d}")
+        else:
+            if d % int(n_chunks) != 0:
+                raise ValueError(f"d = {d} is not divisible into {n_chunks} chunks")
+            widths = [d // int(n_chunks)] * int(n_chunks)
+        self.widths = widths
+        self.offsets = [sum(widths[:c]) for c in range(len(widths))]
         self.plan = plan
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
-        self.n, self.d, self.C = int(n_rows_global), int(d), int(n_chunks)
-        self.dc = self.d // self.C
+        self.n, self.d, self.C = int(n_rows_global), int(d), len(widths)
         self.per = rows_per_rank(self.n, self.world)
         self.r0, self.r1 = block_bounds(self.n, self.world, self.rank)
         self.device = device
@@ -115,9 +125,8 @@ class PipelinedHopAggregation:
         self.use_streams = torch.device(device).type == "cuda"  # CPU/gloo (tests): same schedule, no streams
         if self.world > 1:
             self.comm_stream = torch.cuda.Stream(device=device) if self.use_streams else None
-            self.send = [torch.zeros((self.per, self.dc), dtype=torch.float32, device=device) for _ in range(self.C)]
-            self.full = [torch.empty((self.world * self.per, self.dc), dtype=torch.float32, device=device)
-                         for _ in range(self.C)]
+            self.send = [torch.zeros((self.per, w), dtype=torch.float32, device=device) for w in widths]
+            self.full = [torch.empty((self.world * self.per, w), dtype=torch.float32, device=device) for w in widths]
             if self.use_streams:
                 self.staged = torch.cuda.Event()
                 self.ready = [torch.cuda.Event() for _ in range(self.C)]
@@ -141,17 +150,17 @@ class PipelinedHopAggregation:
         H = self.plan.n_hops
         if out is None:
             out = torch.empty((n_local, H, self.d), dtype=torch.float32, device=self.device)
-        dc = self.dc
+        cols = [slice(o, o + w) for o, w in zip(self.offsets, self.widths)]
         if self.world == 1:
             for c in range(self.C):  # chunked on one GPU: same schedule without the exchange
-                self._spmm(x_local[:, c * dc:(c + 1) * dc], out[:, :, c * dc:(c + 1) * dc])
+                self._spmm(x_local[:, cols[c]], out[:, :, cols[c]])
             return out
         for c in range(self.C):
-            self.send[c][:n_local].copy_(x_local[:, c * dc:(c + 1) * dc])
+            self.send[c][:n_local].copy_(x_local[:, cols[c]])
         if not self.use_streams:
             for c in range(self.C):
                 self._gather(self.full[c], self.send[c], self.group)
-                self._spmm(self.full[c][: self.n], out[:, :, c * dc:(c + 1) * dc])
+                self._spmm(self.full[c][: self.n], out[:, :, cols[c]])
             return out
         main = torch.cuda.current_stream(self.device)
         self.staged.record(main)
@@ -162,7 +171,7 @@ class PipelinedHopAggregation:
                 self.ready[c].record(self.comm_stream)
         for c in range(self.C):
             main.wait_event(self.ready[c])
-            self._spmm(self.full[c][: self.n], out[:, :, c * dc:(c + 1) * dc])
+            self._spmm(self.full[c][: self.n], out[:, :, cols[c]])
         return out
 
 

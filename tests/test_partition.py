@@ -76,7 +76,7 @@ def _worker(rank, world, port, n, d, out_dir):
             def spmm_t(grad):
                 return torch.from_numpy(og.gcn_layer_grad_c(shard, grad.numpy(), n))
 
-        for chunks in (1, 2, 4):
+        for chunks in (1, 2, 4, [4, 4, 8]):
             for exchange in ("allgather", "p2p"):
                 layer = PipelinedHopAggregation(OraclePlan, n, d, chunks, "cpu", exchange=exchange)
                 y_pipe = layer(x_local)
