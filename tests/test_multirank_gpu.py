@@ -126,5 +126,7 @@ def test_row_partitioned_training_matches_single_process(tmp_path):
             assert "Epoch: 0006" in outs[0] and "Epoch: 0006" not in outs[1]  # only rank 0 prints
     a, b = results[1], results[2]
     assert a["train_loss"] < 1.95
-    for k in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_accuracy"):
+    for k in ("train_loss", "val_loss", "test_loss"):       # continuous: must track closely
         assert abs(a[k] - b[k]) <= 2e-3, (k, a[k], b[k])
+    for k in ("train_acc", "val_acc", "test_accuracy"):     # argmax flips of single nodes are allowed early on
+        assert abs(a[k] - b[k]) <= 0.02, (k, a[k], b[k])

@@ -383,6 +383,7 @@ def test_soak_repeated_launches_are_bitwise_stable():
     w = synth.synth_features(256, 8, 0, n, device).view(n, 2, 128)
     y0, g0 = plan.spmm(x).clone(), plan.spmm_t(w).clone()
     side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())  # w / x were produced on the main stream
     for i in range(100):
         y = plan.spmm(x)
         with torch.cuda.stream(side):   # same plan, another stream, at the same time
