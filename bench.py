@@ -143,7 +143,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("H2GCN_DIST_BACKEND", "nccl")  # "gloo" only for the shared-GPU debugging mode
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            from h2gcn_amd.partition import init_rccl_process_group
+            init_rccl_process_group(device)
         else:
             dist.init_process_group(backend)
 

@@ -20,6 +20,18 @@ import torch
 import torch.distributed as dist
 
 
+def init_rccl_process_group(device: torch.device) -> None:
+    """``torch.distributed`` over RCCL with a HIGH-PRIORITY communication stream: the exchange kernels must be
+    scheduled promptly while a 150k-workgroup SpMM grid saturates every CU, otherwise the pipelining of
+    :class:`PipelinedHopAggregation` degenerates into serial execution."""
+    try:
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        dist.init_process_group("nccl", device_id=device, pg_options=opts)
+    except (AttributeError, TypeError):  # older torch: no options object
+        dist.init_process_group("nccl", device_id=device)
+
+
 def block_bounds(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
     """[r0, r1) of ``rank``'s row block: equal blocks of ceil(n/P) rows."""
     if world_size < 1 or not (0 <= rank < world_size):
@@ -124,7 +136,8 @@ class PipelinedHopAggregation:
             raise ValueError(f"plan is {plan.n_rows} x {plan.n_cols}, expected {self.r1 - self.r0} x {self.n}")
         self.use_streams = torch.device(device).type == "cuda"  # CPU/gloo (tests): same schedule, no streams
         if self.world > 1:
-            self.comm_stream = torch.cuda.Stream(device=device) if self.use_streams else None
+            # high priority: its event waits / staging must not queue behind the SpMM grid
+            self.comm_stream = torch.cuda.Stream(device=device, priority=-1) if self.use_streams else None
             self.send = [torch.zeros((self.per, w), dtype=torch.float32, device=device) for w in widths]
             self.full = [torch.empty((self.world * self.per, w), dtype=torch.float32, device=device) for w in widths]
             if self.use_streams:
@@ -199,8 +212,9 @@ def _all_gather_rows_p2p(full: torch.Tensor, send: torch.Tensor, group=None) -> 
         src = (rank - shift) % world
         ops.append(dist.P2POp(dist.isend, send, dst, group))
         ops.append(dist.P2POp(dist.irecv, full[src * per:(src + 1) * per], src, group))
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
 
 
 def _reduce_scatter_rows(full: torch.Tensor, per: int, rank: int, group=None) -> torch.Tensor:

@@ -37,7 +37,8 @@ def init_distributed():
     backend = os.environ.get("H2GCN_DIST_BACKEND", "nccl")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        from .partition import init_rccl_process_group
+        init_rccl_process_group(torch.device("cuda", local))
     else:
         dist.init_process_group(backend)
     import sys
