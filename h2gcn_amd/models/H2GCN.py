@@ -159,12 +159,27 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
             print("Restoring the best performance model")
             print("Best performance:")
             stats_printer.from_dict(args.objects["best_val_stats"])
+            _write_results(args)
         snapshot.write(getattr(args, "checkpoint_dir", None))
 
     args.objects.update(model=model, optimizer=optimizer, checkpoint=snapshot, train_step=train_step,
                         test_step=test_step, predict_step=predict_step, embed_step=embed_step)
     args.objects["post_epoch_callbacks"].append(post_epoch_callback)
     args.objects["post_train_callbacks"].append(post_train_callback)
+
+
+def _write_results(args):
+    """``results.json`` with the best-validation statistics -- the reference writes it into the signac job
+    (``H2GCN.py:186-195``); here it goes to ``--signac_root`` or ``--checkpoint_dir`` when one is given."""
+    import json
+    from pathlib import Path
+
+    target = getattr(args, "_signac_root", None) or getattr(args, "checkpoint_dir", None)
+    if not target:
+        return
+    Path(target).mkdir(parents=True, exist_ok=True)
+    record = {k: (v if isinstance(v, (int, float, str)) else str(v)) for k, v in args.objects["best_val_stats"].items()}
+    (Path(target) / "results.json").write_text(json.dumps(record))
 
 
 def _sharded_steps(model, optimizer):

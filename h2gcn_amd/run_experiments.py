@@ -17,11 +17,33 @@ from . import datasets, models
 from .modules import arguments, logger
 
 
+#: flags of the reference's command line that concern subsystems outside this build (signac bookkeeping, ptvsd,
+#: TF memory growth, IPython, TF checkpoints naming, monitors).  They are accepted so that existing launch lines --
+#: e.g. the ones ``experiments/h2gcn/experiments_workflow.py:301-318`` assembles -- keep working, and ignored.
+COMPAT_FLAGS = (
+    ("--debug", dict(action="store_true")),
+    ("--use_full_gpu", dict(action="store_true", dest="_use_full_gpu")),
+    ("--interactive", dict(action="store_true", dest="_interactive")),
+    ("--use_signac", dict(action="store_true", dest="_compat_use_signac")),
+    ("--signac_root", dict(default=None, dest="_signac_root")),
+    ("--checkpoint_name", dict(type=str, default=None)),
+    ("--message", dict(default=None)),
+    ("--run_id", dict(default=None)),
+    ("--deg_acc_monitor", dict(default=[], type=float, nargs="+")),
+    ("--grad_monitor", dict(action="store_true")),
+    ("--save_activations", dict(action="store_true")),
+    ("--save_predictions", dict(nargs="*", default=True)),
+)
+
+
 def build_parser():
     parser = arguments.create_parser()
     parser.add_argument("--random_seed", type=int, default=123)
     g = parser.add_argument_group("Experiment arguments (run_experiments.py)")
     g.add_argument("--epochs", type=int, default=2000, help="(default: %(default)s)")
+    c = parser.add_argument_group("Accepted for command-line compatibility with the reference, ignored")
+    for flag, kw in COMPAT_FLAGS:
+        c.add_argument(flag, **kw)
     return parser
 
 

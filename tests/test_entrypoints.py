@@ -117,3 +117,29 @@ def test_model_width_tracking_matches_oracle_forward():
         weights = [rng.standard_normal(tuple(l.kernel.shape)) for l in m.regularized]
         enc = [[k, {kk: ({"__set__": sorted(v)} if isinstance(v, set) else v) for kk, v in c.items()}] for k, c in setup]
         assert om.forward(enc, feats, hops, weights).shape == (12, 7)
+
+
+def test_reference_launch_line_flags_are_accepted():
+    """The argv the reference's orchestrator builds (experiments/h2gcn/run_hgcn_experiments.py:13-29 +
+    configs' model_args) parses: bookkeeping flags outside this build are accepted and ignored."""
+    from h2gcn_amd import run_experiments
+    from h2gcn_amd.models import H2GCN as plugin
+    from h2gcn_amd.datasets import planetoid
+    from h2gcn_amd.modules import logger
+
+    parser = run_experiments.build_parser()
+    parser.add_argument("model")
+    parser.add_argument("datafmt")
+    plugin.add_subparser_args(parser)
+    planetoid.add_subparser_args(parser)
+    logger.add_subparser_args(parser)
+    parser.function_hooks["argparse"].clear()  # parse only, no data / model construction
+    argv = ["H2GCN", "planetoid", "--dataset_path", "/data/syn", "--dataset", "syn-products-h0.2", "--run_id=7",
+            "--use_signac", "--signac_root", "/tmp/ws", "--exp_tags", "a", "b", "--val_size", "500",
+            "--network_setup", "M64-R-T1-G-V-T2-G-V-C1-C2-D0.5-MO", "--adj_nhood", "1", "2",
+            "--l2_regularize_weight", "1e-5", "--no_feature_normalize", "--early_stopping", "40", "--grad_monitor",
+            "--deg_acc_monitor", "0.5", "--save_activations", "-v"]
+    args = arguments.parse_args(parser, argv)
+    assert args.dataset == "syn-products-h0.2" and args._dataset_path == "/data/syn" and args.val_size == 500
+    assert args.l2_regularize_weight == 1e-5 and args.no_feature_normalize and args.early_stopping == 40
+    assert args._signac_root == "/tmp/ws" and args.verbose and args._exp_tags == ["a", "b"]
