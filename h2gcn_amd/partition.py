@@ -141,7 +141,7 @@ class PipelinedHopAggregation:
             self.send = [torch.zeros((self.per, w), dtype=torch.float32, device=device) for w in widths]
             self.full = [torch.empty((self.world * self.per, w), dtype=torch.float32, device=device) for w in widths]
             if self.use_streams:
-                self.staged = torch.cuda.Event()
+                self.staged = [torch.cuda.Event() for _ in range(self.C)]
                 self.ready = [torch.cuda.Event() for _ in range(self.C)]
         #: set to a list to have (start, end) timing-event pairs appended around every SpMM launch
         self.kernel_events = None
@@ -168,18 +168,19 @@ class PipelinedHopAggregation:
             for c in range(self.C):  # chunked on one GPU: same schedule without the exchange
                 self._spmm(x_local[:, cols[c]], out[:, :, cols[c]])
             return out
-        for c in range(self.C):
-            self.send[c][:n_local].copy_(x_local[:, cols[c]])
         if not self.use_streams:
             for c in range(self.C):
+                self.send[c][:n_local].copy_(x_local[:, cols[c]])
                 self._gather(self.full[c], self.send[c], self.group)
                 self._spmm(self.full[c][: self.n], out[:, :, cols[c]])
             return out
         main = torch.cuda.current_stream(self.device)
-        self.staged.record(main)
+        for c in range(self.C):  # stage chunk by chunk so that the first exchange can start after the first copy
+            self.send[c][:n_local].copy_(x_local[:, cols[c]])
+            self.staged[c].record(main)
         with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(self.staged)
             for c in range(self.C):
+                self.comm_stream.wait_event(self.staged[c])
                 self._gather(self.full[c], self.send[c], self.group)
                 self.ready[c].record(self.comm_stream)
         for c in range(self.C):
