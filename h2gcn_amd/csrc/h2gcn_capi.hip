@@ -180,7 +180,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 // working set of one slice (n_src_rows * slice * 4 B) is friendlier to the 256 MiB Infinity Cache when the whole
 // operand is far beyond it.  `forced` > 0 (plan option) overrides the heuristic.
 int pick_slice_cols(int d, int64_t n_src_rows, int forced, double avg_segment_nnz) {
-    static const int widths[] = {256, 128, 64, 32};
+    static const int widths[] = {256, 128, 64, 32, 16};
     if (forced > 0 && d % forced == 0) return forced;  // a forced width that does not divide d falls back to the heuristic
     int best = 0;
     for (int w : widths) {
@@ -233,6 +233,8 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
         H2GCN_LAUNCH(4, 16, true);
     } else if (slice == 32) {
         H2GCN_LAUNCH(4, 8, true);
+    } else if (slice == 16) {
+        H2GCN_LAUNCH(4, 4, true);  // 64-byte rows, 16 neighbours per load instruction (narrow exchange chunks)
     } else if (vec_ok && p.d % 4 == 0) {
         H2GCN_LAUNCH(4, 64, false);
     } else {
@@ -293,8 +295,9 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
                 return fail(H2GCN_ERR_INVALID_ARGUMENT, "opts->struct_size = %u", opts->struct_size);
             memcpy(&o, opts, opts->struct_size);
         }
-        if (o.slice_cols != 0 && o.slice_cols != 32 && o.slice_cols != 64 && o.slice_cols != 128 && o.slice_cols != 256)
-            return fail(H2GCN_ERR_INVALID_ARGUMENT, "slice_cols = %d, supported 0 (auto), 32, 64, 128, 256", o.slice_cols);
+        if (o.slice_cols != 0 && o.slice_cols != 16 && o.slice_cols != 32 && o.slice_cols != 64 && o.slice_cols != 128 &&
+            o.slice_cols != 256)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "slice_cols = %d, supported 0 (auto), 16, 32, 64, 128, 256", o.slice_cols);
         if (o.long_row_threshold < 0 || o.rows_per_wave < 0 || o.rows_per_wave > h2gcn::kMaxRowsPerWave)
             return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad tunable (long_row_threshold %d, rows_per_wave %d, max %d)",
                         o.long_row_threshold, o.rows_per_wave, h2gcn::kMaxRowsPerWave);

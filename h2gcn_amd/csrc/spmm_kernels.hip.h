@@ -117,11 +117,18 @@ __device__ __forceinline__ float fold_xor8(float v) {
     return v + __int_as_float(o);
 }
 
+// sum over the four lanes {l, l+4, l+8, l+12} (mod 16) of a row: after fold_xor8, one DPP row_ror:4 completes it
+__device__ __forceinline__ float fold_ror4(float v) {
+    const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124 /* row_ror:4 */, 0xf, 0xf, false);
+    return v + __int_as_float(o);
+}
+
 // Fold the partial sums of the G = 64/LPR lane groups; afterwards every group holds the total.
 // Fixed tree: (g, g^1) first ... independent of anything but LPR.
 template <int LPR>
 __device__ __forceinline__ float fold_groups(float v) {
     if constexpr (LPR <= 8) v = fold_xor8(v);
+    if constexpr (LPR <= 4) v = fold_ror4(v);
     if constexpr (LPR <= 16) v = fold_xor16(v);
     if constexpr (LPR <= 32) v = fold_xor32(v);
     return v;

@@ -67,7 +67,7 @@ typedef struct h2gcn_plan_opts {
     int32_t variant;             /* kernel variant: 0 = default (index prefetch across segments when segments
                                     average < 16 nonzeros); 1 = scalar-addressed float2 gathers at d=128;
                                     2 = always prefetch; 3 = never prefetch                                   */
-    int32_t slice_cols;          /* feature columns per slice of the slice-major schedule: 32/64/128/256,
+    int32_t slice_cols;          /* feature columns per slice of the slice-major schedule: 16/32/64/128/256,
                                     0 = heuristic (narrower slices when X is far beyond the Infinity Cache)  */
     int32_t reserved[2];
 } h2gcn_plan_opts;
@@ -129,8 +129,9 @@ int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t*
  *
  *   X_dev   fp32, n_cols rows of d values, row stride ldx >= d (elements)
  *   Y_dev   fp32, must not alias X
- *   d       feature width >= 1.  Fast paths: d in {32,64,128,256} with 16-byte aligned X/Y and strides that
- *           are multiples of 4; anything else takes the generic column-tiled path (same results).
+ *   d       feature width >= 1.  Fast paths: d a multiple of 16 with 16-byte aligned X/Y and strides that are
+ *           multiples of 4 (processed in column slices of 16..256); anything else takes the generic column-tiled
+ *           path (same results).
  */
 int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X_dev, int64_t ldx,
                         int32_t d, float* Y_dev, int64_t ldy_row, int64_t ldy_hop, void* stream);

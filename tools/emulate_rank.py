@@ -22,7 +22,7 @@ for P in (1, 2, 4, 8):
     plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n)
     y = torch.empty((r1 - r0, 2, d), device=dev)
     res = {}
-    for C in (1, 2, 4):
+    for C in (1, 2, 4, 8):
         dc = d // C
         xb = [x[:, c * dc:(c + 1) * dc].contiguous() for c in range(C)]   # what the all-gather delivers
         res[C] = t(lambda: [plan.spmm(xb[c], out=y[:, :, c * dc:(c + 1) * dc]) for c in range(C)])
