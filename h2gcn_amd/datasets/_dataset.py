@@ -124,6 +124,21 @@ class PlanetoidData:
         self.features = sp.identity(self.num_samples, dtype=np.float32, format="csr")
 
     # ------------------------------------------------------------------ tensors
+    #: features denser than this are handed to the model as a dense matrix: X @ W0 is then GEMM-shaped work for
+    #: rocBLAS / hipBLASLt (MFMA), not a gather (syn-products has F = 100 dense features)
+    DENSE_FEATURE_THRESHOLD = 0.25
+
+    def _feature_operand(self, features, device, build_transpose):
+        import torch
+
+        from ..hops import HopPlan
+
+        f = sp.csr_matrix(features)
+        density = f.nnz / max(1, f.shape[0] * f.shape[1])
+        if density >= self.DENSE_FEATURE_THRESHOLD:
+            return torch.from_numpy(np.asarray(f.todense(), dtype=np.float32)).to(device)
+        return HopPlan.from_scipy([f], device, build_transpose=build_transpose)
+
     def get_tensors(self, device, adj_norm_hops: Optional[Sequence[str]] = None, norm: str = operands.SYM_NORMALIZED,
                     build_transpose: bool = True, host_hops: bool = False, shard=None) -> dict:
         """``adj`` / ``features`` / ``adj_hops`` as device operands + dense label/mask tensors (keys as the
@@ -138,7 +153,7 @@ class PlanetoidData:
         if shard is not None:
             return self._get_tensors_sharded(device, adj_norm_hops, norm, shard)
         t = {}
-        t["features"] = HopPlan.from_scipy([self.features], device, build_transpose=build_transpose)
+        t["features"] = self._feature_operand(self.features, device, build_transpose)
         t["adj"] = HopPlan.from_scipy([self.sparse_adj], device)
         if adj_norm_hops and host_hops:      # scipy SpGEMM on the host, as the reference does
             hops = operands.build_adj_norm_hops(self.sparse_adj, adj_norm_hops, norm)
@@ -166,7 +181,7 @@ def _sharded_tensors(self, device, adj_norm_hops, norm, shard):
     n = self.num_samples
     r0, r1 = block_bounds(n, world, rank)
     t = {"adj": None}
-    t["features"] = HopPlan.from_scipy([sp.csr_matrix(self.features)[r0:r1]], device, build_transpose=True)
+    t["features"] = self._feature_operand(sp.csr_matrix(self.features)[r0:r1], device, True)
     if adj_norm_hops:
         rp, ci, va, _ = operands.build_adj_norm_hops_device(self.sparse_adj, adj_norm_hops, norm, device)
         parts = [slice_csr_rows(rp[k], ci[k], va[k], r0, r1) for k in range(len(rp))]

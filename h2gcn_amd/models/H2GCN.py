@@ -84,8 +84,11 @@ def make_optimizer(name: str, params, lr: float, capturable: bool = False):
 def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, early_stopping):
     tensors = args.objects["tensors"]
     device = torch.device(args._device)
-    model = H2GCN(layer_setups, input_dim=tensors["features"].n_cols, n_hops=(tensors["adj_hops"].n_hops
-                  if tensors["adj_hops"] is not None else 0), l2_regularize_weight=l2_regularize_weight).to(device)
+    feats = tensors["features"]
+    dense_features = isinstance(feats, torch.Tensor)  # dense-ish features arrive as a matrix (GEMM path)
+    model = H2GCN(layer_setups, input_dim=(feats.shape[1] if dense_features else feats.n_cols),
+                  n_hops=(tensors["adj_hops"].n_hops if tensors["adj_hops"] is not None else 0),
+                  sparse_input=not dense_features, l2_regularize_weight=l2_regularize_weight).to(device)
     sharded = _is_sharded()
     use_graphs = not getattr(args, "_no_hipgraph", False) and optimizer.lower() == "adam" and not sharded
     optimizer = make_optimizer(optimizer, model.parameters(), lr, capturable=use_graphs)

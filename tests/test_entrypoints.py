@@ -143,3 +143,17 @@ def test_reference_launch_line_flags_are_accepted():
     assert args.dataset == "syn-products-h0.2" and args._dataset_path == "/data/syn" and args.val_size == 500
     assert args.l2_regularize_weight == 1e-5 and args.no_feature_normalize and args.early_stopping == 40
     assert args._signac_root == "/tmp/ws" and args.verbose and args._exp_tags == ["a", "b"]
+
+
+def test_dense_features_are_not_wrapped_as_sparse_operands(tmp_path):
+    """Feature matrices denser than 25 % are kept dense (GEMM-shaped embedding); sparse ones become a 1-hop
+    operand -- decided without touching the GPU."""
+    from h2gcn_amd.datasets._dataset import PlanetoidData
+
+    f_dense = sp.csr_matrix(np.random.default_rng(0).standard_normal((6, 5)).astype(np.float32))
+    dummy = PlanetoidData.__new__(PlanetoidData)
+    out = dummy._feature_operand(f_dense, "cpu", True)
+    assert isinstance(out, torch.Tensor) and out.shape == (6, 5)
+    f_sparse = sp.random(50, 40, 0.05, format="csr", random_state=0, dtype=np.float32)
+    with pytest.raises(ValueError, match="GPU"):   # sparse -> HopPlan, which refuses CPU tensors (no fallback)
+        dummy._feature_operand(f_sparse, "cpu", True)

@@ -96,6 +96,13 @@ def test_syn_products_h2gcn2_logits(tmp_path):
     assert np.abs(logits.cpu().numpy() - want).max() <= 1e-5 * scale
     assert np.abs(tagged["2"].cpu().numpy() - want_tagged["2"]).max() <= 1e-5 * max(1.0, np.abs(want_tagged["2"]).max())
     assert plan.nnz == [h.nnz for h in ohops]
+    # dense-ish features take the GEMM path (dense operand, rocBLAS) -- same logits
+    torch.manual_seed(1)
+    dense_model = H2GCN(setup, input_dim=100, n_hops=2, sparse_input=False, l2_regularize_weight=5e-4).to(dev).eval()
+    dense_model.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        logits_dense = dense_model(None, torch.from_numpy(feats).to(dev), plan)
+    assert (logits_dense - logits).abs().max().item() <= 1e-4 * scale
 
 
 def test_device_built_hops_equal_host_built(tmp_path):
