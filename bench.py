@@ -48,8 +48,7 @@ def pmc_traffic(shape, d, chunks, slice_cols, world):
     except Exception:
         return None
     key = f"{shape}|d={d}|chunks={chunks}|slice={slice_cols or 'auto'}|gpus={world}"
-    e = table.get(key)
-    return None if e is None else e.get("bytes_per_launch")
+    return table.get(key)
 
 
 def cpu_baseline(plan_csr, x_full, d, target_seconds=12.0):
@@ -107,22 +106,48 @@ def cpu_baseline(plan_csr, x_full, d, target_seconds=12.0):
     return res
 
 
+def probe_ceilings(table_mib, row_bytes):
+    """Live ceilings of THIS box from tools/gather_probe (built by __graft_entry__.build(); micro-benchmark, not
+    product): random `row_bytes`-row gathers out of a `table_mib` MiB table (what the SpMM's gather stream can
+    reach at its working-set size) and a plain stream copy (the achievable HBM rate)."""
+    import subprocess
+    exe = ROOT / "tools" / "gather_probe"
+    if not exe.exists():
+        return {"error": "tools/gather_probe not built"}
+    try:
+        out = subprocess.run([str(exe), "--point", str(int(table_mib)), str(int(row_bytes))], capture_output=True,
+                             text=True, timeout=120).stdout
+        return json.loads(out.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001 -- a report, never a reason to lose the GPU number
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def parse_chunks(spec, d):
+    """'2' -> 2 equal chunks; '32+32+64' -> explicit widths."""
+    spec = str(spec)
+    if "+" in spec:
+        return [int(w) for w in spec.split("+")]
+    return int(spec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--shape", default="products", choices=["products", "arxiv", "lowdeg"])
+    ap.add_argument("--shape", default="products", choices=sorted(__import__("h2gcn_amd.synth", fromlist=["SHAPES"]).SHAPES))
     ap.add_argument("--d", type=int, default=0, help="feature width (default: the shape's, 128)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--long-row-threshold", type=int, default=0)
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--slice-cols", type=int, default=0, help="feature columns per slice (0 = library heuristic)")
-    ap.add_argument("--chunks", type=int, default=-1,
-                    help="feature chunks of the pipelined all-gather/SpMM (default: 1 on one GPU; on several, the "
-                         "fastest of 1/2/4 as timed during warm-up)")
-    ap.add_argument("--adjoint", action="store_true", help="also time the backward (adjoint) launch; extra, not the metric")
+    ap.add_argument("--chunks", default="",
+                    help="feature chunks of the pipelined exchange/SpMM: a count ('2') or explicit widths ('32+32+64'). "
+                         "Default: 1 on one GPU; on several, the fastest candidate as timed during warm-up")
+    ap.add_argument("--exchange", default="", help="allgather | p2p | ipc_engine | ipc_kernel (default: calibrate)")
+    ap.add_argument("--no-adjoint", action="store_true", help="skip the (untimed, secondary) adjoint launch figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="skip the live gather/copy ceiling probe")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
 
@@ -135,18 +160,21 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: h2gcn_amd has no CPU fallback")
-    if os.environ.get("H2GCN_SHARE_GPU") == "1":  # debugging aid: several ranks on one GPU (if RCCL allows it)
+    if os.environ.get("H2GCN_SHARE_GPU") == "1":  # test mode: several ranks on one GPU (RCCL refuses that -> gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("H2GCN_DIST_BACKEND", "nccl")  # "gloo" only for the shared-GPU debugging mode
+        backend = os.environ.get("H2GCN_DIST_BACKEND", "nccl")  # "gloo" only for the shared-GPU test mode
+        timeout_s = float(os.environ.get("H2GCN_DIST_TIMEOUT_S", "300"))  # a failed rank must not hang its peers forever
         if backend == "nccl":
             from h2gcn_amd.partition import init_rccl_process_group
-            init_rccl_process_group(device)
+            init_rccl_process_group(device, timeout_s)
         else:
-            dist.init_process_group(backend)
+            import datetime
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s))
 
     from h2gcn_amd import HopPlan, synth
     from h2gcn_amd.partition import PipelinedHopAggregation, block_bounds
@@ -160,7 +188,7 @@ def main():
     torch.cuda.synchronize()
     plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n,
                    variant=a.variant, long_row_threshold=a.long_row_threshold, rows_per_wave=a.rows_per_wave,
-                   slice_cols=a.slice_cols, build_transpose=a.adjoint)
+                   slice_cols=a.slice_cols, build_transpose=not a.no_adjoint)
     x_local = synth.synth_features(d, synth.SEED_X, r0, r1, device)
     y = torch.empty((r1 - r0, 2, d), dtype=torch.float32, device=device)
     nnz_local = plan.nnz
@@ -186,49 +214,75 @@ def main():
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
         return float(v.item())
 
-    # Exchange schedule.  On one GPU: a single fused launch.  On several: the all-gather is pipelined against the
-    # SpMM in feature chunks; how many chunks pay off depends on the node's RCCL/xGMI rates, so (unless --chunks is
-    # given) the candidates are timed during warm-up and the fastest is used for the measured steps.  The
-    # calibration numbers and the comm-only / compute-only times are reported as diagnostics.
-    fallback, diagnostics = None, {}
-    if a.chunks > 0 or world == 1:
-        chunks = a.chunks if a.chunks > 0 else 1
+    def all_ok(flag):
+        """True iff `flag` holds on every rank (a candidate must be valid everywhere before it is used)."""
+        t = torch.tensor([1.0 if flag else 0.0], device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0)
+
+    # Exchange schedule.  On one GPU: a single fused launch.  On several: the exchange is pipelined against the SpMM
+    # in feature chunks; which exchange (one ncclAllGather / P-1 grouped ncclSend+ncclRecv / IPC copy-engine pulls /
+    # IPC copy-kernel pulls) and how many chunks pay off depends on the node's RCCL/xGMI rates, so -- unless forced
+    # by --exchange/--chunks -- the candidates are timed during warm-up and the fastest is used for the measured
+    # steps.  Construction is collectively safe (every rank reports, all agree before a candidate runs); the
+    # calibration table and the comm-only / compute-only times are reported as diagnostics.
+    rejected, diagnostics = {}, {}
+    if world == 1:
+        chunks = parse_chunks(a.chunks, d) if a.chunks else 1
         layer = PipelinedHopAggregation(plan, n, d, chunks, device)
+        exchange = None
     else:
+        exchanges = [a.exchange] if a.exchange else os.environ.get(
+            "H2GCN_BENCH_EXCHANGES", "allgather,p2p,ipc_engine,ipc_kernel").split(",")
+        chunk_specs = [a.chunks] if a.chunks else ["1", "2", "4", "32+32+64"]
         cands = {}
-        for exchange in ("allgather", "p2p"):       # one ncclAllGather vs P-1 grouped ncclSend/ncclRecv per rank
-            for c in (1, 2, 4, "32+32+64"):
-                if isinstance(c, int) and (d % c or d // c < 32):
+        for ex in exchanges:
+            for spec in chunk_specs:
+                widths = parse_chunks(spec, d)
+                if isinstance(widths, int) and (d % widths or d // widths < 32):
                     continue
-                if isinstance(c, str) and d != 128:
+                if isinstance(widths, list) and sum(widths) != d:
                     continue
-                widths = c if isinstance(c, int) else [int(w) for w in c.split("+")]
-                ok = torch.ones(1, device=device)
+                key = f"{ex}/{spec}"
+                cand, why = None, None
                 try:
-                    cand = PipelinedHopAggregation(plan, n, d, widths, device, exchange=exchange)
+                    cand = PipelinedHopAggregation(plan, n, d, widths, device, exchange=ex)
+                except Exception as e:  # noqa: BLE001 -- unavailable on this node/backend: not a candidate
+                    why = f"construct: {type(e).__name__}: {e}"
+                if not all_ok(cand is not None):
+                    rejected[key] = why or "construction failed on another rank"
+                    if cand is not None:
+                        cand.ipc = None if cand.ipc is None else cand.ipc._destroy_local()
+                    continue
+                try:
                     for _ in range(2):
                         cand(x_local, out=y)
                     torch.cuda.synchronize()
-                except Exception as e:  # a schedule that is unavailable on this node is simply not a candidate
-                    fallback = f"{exchange} chunks={c}: {type(e).__name__}: {e}"
-                    ok.zero_()
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank must agree before timing it
-                if ok.item() > 0:
-                    cands[(exchange, c)] = (timed_ms(lambda: cand(x_local, out=y), 3), cand)
+                    if cand.ipc is not None:
+                        cand.ipc.check()
+                except Exception as e:  # noqa: BLE001
+                    why = f"warm-up: {type(e).__name__}: {e}"
+                if not all_ok(why is None):
+                    rejected[key] = why or "warm-up failed on another rank"
+                    continue
+                cands[key] = (timed_ms(lambda: cand(x_local, out=y), 3), cand, ex, spec)
         if not cands:
-            raise SystemExit(f"no exchange schedule works: {fallback}")
+            raise SystemExit(f"no exchange schedule works: {rejected}")
         best = min(cands, key=lambda k: cands[k][0])
-        exchange, chunks = best
-        layer = cands[best][1]
+        _, layer, exchange, spec = cands[best]
+        chunks = parse_chunks(spec, d)
         diagnostics["exchange"] = exchange
-        diagnostics["calibration_ms_per_step"] = {f"{e}/{c}": v[0] for (e, c), v in cands.items()}
-        # comm-only and compute-only times of the chosen chunking (not part of the metric)
-        if hasattr(layer, "full"):
-            diagnostics["exchange_only_ms"] = timed_ms(
-                lambda: [layer._gather(layer.full[c], layer.send[c], None) for c in range(layer.C)], 3)
-            diagnostics["spmm_only_ms"] = timed_ms(
-                lambda: [plan.spmm(layer.full[c][:n], out=y[:, :, layer.offsets[c]:layer.offsets[c] + layer.widths[c]])
-                         for c in range(layer.C)], 3)
+        diagnostics["calibration_ms_per_step"] = {k: v[0] for k, v in cands.items()}
+        diagnostics["rejected"] = rejected
+        # comm-only and compute-only times of the chosen schedule (not part of the metric)
+        diagnostics["exchange_only_ms"] = timed_ms(layer.exchange_only, 3)
+        diagnostics["spmm_only_ms"] = timed_ms(
+            lambda: [plan.spmm(layer.full[c][:n], out=y[:, :, layer.offsets[c]:layer.offsets[c] + layer.widths[c]])
+                     for c in range(layer.C)], 3)
+        for k, v in cands.items():  # collective: release the exported buffers of the schedules not chosen
+            if v[1] is not layer:
+                v[1].close()
         del cands
     for _ in range(max(a.warmup, 1)):
         layer(x_local, out=y)
@@ -238,23 +292,36 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        layer(x_local, out=y)      # [staging + all-gather chunks on the side stream] + `chunks` fused SpMM launches
+        layer(x_local, out=y)      # [staging + exchange of the chunks, overlapped] + `chunks` fused SpMM launches
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    # per-step kernel time = sum over the step's `chunks` launches (one launch when chunks == 1)
-    kern_ms = float(np.sum([s.elapsed_time(e) for s, e in layer.kernel_events])) / a.steps
+    if layer.ipc is not None:
+        layer.ipc.check()
+    # per-step kernel time = sum over the step's `chunks` launches (one launch when chunks == 1); mean for the
+    # roofline (comparable with rocprofv3's average), median as SURVEY 8(d) defines t_fused
+    per_launch = np.array([s_.elapsed_time(e_) for s_, e_ in layer.kernel_events], dtype=np.float64)
+    per_step = per_launch.reshape(a.steps, layer.C).sum(1)
+    kern_ms, kern_ms_median = float(per_step.mean()), float(np.median(per_step))
     kt = torch.tensor([kern_ms], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
     kern_ms_max = float(kt.item())
+    # order-independent fingerprint of the result (same schedule => same bits for any number of ranks)
+    ck = y.view(torch.int32).to(torch.int64).sum()
+    if world > 1:
+        dist.all_reduce(ck)
+    y_checksum = int(ck.item())
 
     edges = sum(nnz_global)
     b_alg = algorithmic_bytes(nnz_local, r1 - r0, d, 2)
+    b_min = compulsory_bytes(nnz_local, r1 - r0, n, d, 2)
     achieved = b_alg / (kern_ms * 1e-3) / 1e9
+    chunk_label = chunks if isinstance(chunks, int) else "+".join(str(w) for w in chunks)
+    traffic = pmc_traffic(a.shape, d, chunk_label, a.slice_cols, world)
     out = {
         "metric": "aggregated edges/sec (1+2-hop SpMM)",
         "value": edges * a.steps / elapsed,
@@ -272,36 +339,57 @@ def main():
                         + f": synthetic CSR |V|={n}, nnz(A1)={nnz_global[0]}, nnz(A2)={nnz_global[1]}, d={d}, "
                           "row-normalised values 1/deg, 2-hop CSR supplied (not derived)",
             "n_rows": n, "nnz_per_hop": nnz_global, "d": d,
-            "parallelism": f"row-partition x{world}" + (", RCCL all-gather of X per step" if world > 1 else ""),
-            "kernel_variant": a.variant, "feature_chunks": chunks, "pipeline_fallback": fallback,
-            "diagnostics": diagnostics, "slice_cols": a.slice_cols or "auto",
+            "parallelism": f"row-partition x{world}" + (f", exchange of X per step: {exchange}" if world > 1 else ""),
+            "kernel_variant": a.variant, "feature_chunks": chunk_label, "dist_backend": backend,
+            "diagnostics": diagnostics, "slice_cols": a.slice_cols or "auto", "y_checksum": y_checksum,
+            "t_fused_median_ms": kern_ms_median,
+            "edges_per_s_from_median_kernel_time": sum(nnz_local) / (kern_ms_median * 1e-3),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": pmc_traffic(a.shape, d, chunks, a.slice_cols, world),
+            "traffic": None if traffic is None else traffic["bytes_per_launch"],
+            "traffic_source": None if traffic is None else
+                f"offline rocprofv3 PMC passes of the same command ({traffic.get('source')}); NOT collected by this run",
+            "achieved_is": "ALGORITHMIC (no-reuse) bytes per launch / mean kernel time: it counts every gathered feature "
+                           "row as memory traffic, so L2 and Infinity-Cache (MALL) hits are included -- it is the "
+                           "delivered gather rate, not a DRAM-pin rate; compare with gather_ceiling_GBps",
             "kernel": "h2gcn::spmm_hops_kernel (fused 1+2-hop)"
                       + (f", {layer.C} launches over column chunks {layer.widths}" if layer.C > 1 else ""),
-            "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_max,
+            "kernel_ms": kern_ms, "kernel_ms_median": kern_ms_median, "kernel_ms_max_over_ranks": kern_ms_max,
             "algorithmic_bytes_per_launch": b_alg,
-            "compulsory_bytes_per_launch": compulsory_bytes(nnz_local, r1 - r0, n, d, 2),
+            "compulsory_bytes_per_launch": b_min,
+            "compulsory_frac": b_min / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         },
     }
-    if a.adjoint:
-        # backward launch dX = sum_k A_k^T dY[:, k, :] on the local shard (secondary figure, untimed by the metric)
+    if not a.no_adjoint:
+        # backward launch dX = sum_k A_k^T dY[:, k, :] on the local shard: half of every training step
+        # (reference h2gcn/models/H2GCN.py:66-74); secondary figure, not part of the metric
         dy = synth.synth_features(2 * d, 77, r0, r1, device).view(r1 - r0, 2, d)
         for _ in range(3):
             plan.spmm_t(dy)
         evs = []
         for _ in range(10):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record(); plan.spmm_t(dy); e.record()
-            evs.append((s, e))
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record(); plan.spmm_t(dy); e_.record()
+            evs.append((s_, e_))
         torch.cuda.synchronize()
-        adj_ms = float(np.mean([s.elapsed_time(e) for s, e in evs]))
+        adj = np.array([s_.elapsed_time(e_) for s_, e_ in evs])
         b_adj = sum(z * (4 + 4 + 4 * d) + (n + 1) * 8 for z in nnz_local) + n * d * 4
-        out["adjoint"] = {"kernel_ms": adj_ms, "algorithmic_bytes_per_launch": b_adj,
-                          "achieved_GBps": b_adj / (adj_ms * 1e-3) / 1e9, "frac": b_adj / (adj_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        out["adjoint"] = {"kernel": "h2gcn::spmm_hops_kernel SUM mode on plan-owned A_k^T (local shard)",
+                          "kernel_ms": float(adj.mean()), "kernel_ms_median": float(np.median(adj)),
+                          "algorithmic_bytes_per_launch": b_adj,
+                          "achieved_GBps": b_adj / (adj.mean() * 1e-3) / 1e9,
+                          "frac": b_adj / (adj.mean() * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                          "edges_per_s": sum(nnz_local) / (adj.mean() * 1e-3)}
+        del dy
+    if rank == 0 and world == 1 and not a.no_probe:
+        # live ceilings of this box at the kernel's gather working set (one column slice of X)
+        slice_cols = a.slice_cols or (64 if (d % 64 == 0 and n * 128 * 4 > 768 * 2**20 and d >= 128) else min(d, 256))
+        pr = probe_ceilings(n * slice_cols * 4 / 2**20, slice_cols * 4)
+        out["roofline"]["gather_ceiling_GBps"] = pr.get("gather_GBps")
+        out["roofline"]["peak_achievable"] = pr.get("copy_GBps")
+        out["roofline"]["ceilings"] = pr
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(csr, x_local, d, a.cpu_seconds)
@@ -310,6 +398,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        layer.close()
         dist.destroy_process_group()
 
 

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_HOPS = 8
 
 OK = 0
@@ -21,6 +21,11 @@ ERR_OUT_OF_MEMORY = -3
 ERR_BAD_INDEX = -4
 ERR_NO_TRANSPOSE = -5
 ERR_INTERNAL = -6
+ERR_EXCHANGE_TIMEOUT = -7
+
+XCHG_BLOB_BYTES = 192
+XCHG_COPY_ENGINE = 0
+XCHG_COPY_KERNEL = 1
 
 PLAN_BUILD_TRANSPOSE = 0x1
 PLAN_SKIP_VALIDATION = 0x2
@@ -36,6 +41,13 @@ EXPORTED_SYMBOLS = (
     "h2gcn_plan_info",
     "h2gcn_spmm_hops_f32",
     "h2gcn_spmm_hops_T_f32",
+    "h2gcn_xchg_create",
+    "h2gcn_xchg_export",
+    "h2gcn_xchg_connect",
+    "h2gcn_xchg_allgather_begin",
+    "h2gcn_xchg_allgather_end",
+    "h2gcn_xchg_status",
+    "h2gcn_xchg_destroy",
 )
 
 
@@ -108,6 +120,22 @@ def lib() -> C.CDLL:
     L.h2gcn_spmm_hops_T_f32.argtypes = [
         C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
     ]
+    L.h2gcn_xchg_create.restype = C.c_int
+    L.h2gcn_xchg_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.h2gcn_xchg_export.restype = C.c_int
+    L.h2gcn_xchg_export.argtypes = [C.c_void_p, C.c_void_p]
+    L.h2gcn_xchg_connect.restype = C.c_int
+    L.h2gcn_xchg_connect.argtypes = [C.c_void_p, C.c_void_p]
+    L.h2gcn_xchg_allgather_begin.restype = C.c_int
+    L.h2gcn_xchg_allgather_begin.argtypes = [
+        C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+    ]
+    L.h2gcn_xchg_allgather_end.restype = C.c_int
+    L.h2gcn_xchg_allgather_end.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.h2gcn_xchg_status.restype = C.c_int
+    L.h2gcn_xchg_status.argtypes = [C.c_void_p]
+    L.h2gcn_xchg_destroy.restype = None
+    L.h2gcn_xchg_destroy.argtypes = [C.c_void_p]
     got = L.h2gcn_abi_version()
     if got != ABI_VERSION:
         raise RuntimeError(f"{path}: ABI version {got}, this front end expects {ABI_VERSION}")

@@ -1,0 +1,415 @@
+// exchange.hip -- all-gather of the row-sharded embedding between the GPUs of one node through IPC-exported
+// device buffers (h2gcn_xchg_* in include/h2gcn_hip.h).  No counterpart in the reference (single process, single
+// device); it serves the row partition SURVEY.md 8(e) adds in front of GCNLayer.call
+// (reference h2gcn/models/_layers.py:78-81): every rank needs all of X before its local fused SpMM.
+//
+// Protocol (per channel, sequence number q = 1, 2, ...; every rank runs the same code):
+//   begin:  [stream]      wait for this channel's previous pulls      (so slot q&1, last used by q-2, is free: a
+//                                                                      peer can only have announced q-1 after its
+//                                                                      own pulls of q-2 finished -- no ack needed)
+//           [stream]      stage_kernel: src -> my slot[q&1]  (+ my own block of `full`)
+//           [stream]      signal_kernel: system-scope release, then store q into flag[channel][my rank] of EVERY
+//                         peer (their memory, over xGMI): "my shard q is readable"
+//           [peer stream] wait until flag[channel][peer] >= q (spin on LOCAL fine-grained memory, bounded by a
+//                         wall-clock limit), then copy peer's slot[q&1] -> full[peer block]
+//   end:    [stream]      wait for the pull events of the channel.
+// Pulls are either copy-engine transfers (hipMemcpyAsync on one stream per peer -- on a fully connected xGMI node
+// every peer is its own link, so P-1 transfers run in parallel and no CU is taken from the SpMM) or ONE copy
+// kernel whose workgroups are split over the peers (CU-driven loads over xGMI).
+//
+// Deadlock freedom: signal(q) is enqueued before any wait(q) of the same rank, and everything enqueued before
+// signal(q) depends only on signals < q of the peers -- induction over (step, channel) order, independent of how
+// HIP maps streams onto hardware queues.  A peer that dies leaves waits that give up after `timeout_ms`.
+#include <hip/hip_runtime.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <type_traits>
+#include <vector>
+
+#include "capi_internal.h"
+#include "h2gcn_hip.h"
+
+namespace {
+
+using h2gcn::fail;
+
+constexpr int kMaxWorld = 64;
+constexpr int kMaxChannels = 64;
+constexpr int kPullBlocksPerPeer = 16;  // copy-kernel mode: workgroups per peer
+constexpr int kPullThreads = 256;
+using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
+
+struct Blob {  // what h2gcn_xchg_export writes (H2GCN_XCHG_BLOB_BYTES, POD)
+    hipIpcMemHandle_t data;
+    hipIpcMemHandle_t flags;
+    uint64_t slot_bytes;
+    int32_t world, rank, n_channels, device;
+    int64_t pid;
+    uint32_t magic;
+    uint32_t pad[7];
+};
+static_assert(sizeof(Blob) <= H2GCN_XCHG_BLOB_BYTES, "blob too large");
+constexpr uint32_t kMagic = 0x48324758u;  // "H2GX"
+
+struct PeerTable {  // device-resident copy of the peer pointers (kernel argument by value)
+    char* data[kMaxWorld];
+    uint32_t* flags[kMaxWorld];
+};
+
+// ---- device code ------------------------------------------------------------------------------------------
+
+// src [rows, width] (stride ld_src) -> slot [rows_per_rank, width] and own block of `full`; rows beyond `rows`
+// are written as zeros (short last shard).  width % 4 == 0 and 16-B alignment take the float4 path.
+template <bool VEC4>
+__global__ void stage_kernel(const float* __restrict__ src, int64_t ld_src, int64_t rows, int64_t rows_per_rank,
+                             int width, float* __restrict__ slot, float* __restrict__ own) {
+    using T = typename std::conditional<VEC4, float4, float>::type;
+    const int wv = VEC4 ? width / 4 : width;
+    const int64_t total = rows_per_rank * wv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / wv;
+        const int c = (int)(i - r * wv);
+        T v;
+        if constexpr (VEC4) v = make_float4(0.f, 0.f, 0.f, 0.f); else v = 0.f;
+        if (r < rows) v = *reinterpret_cast<const T*>(src + r * ld_src + (int64_t)c * (VEC4 ? 4 : 1));
+        reinterpret_cast<T*>(slot)[i] = v;
+        reinterpret_cast<T*>(own)[i] = v;
+    }
+}
+
+// "my shard `seq` of `channel` is readable": release everything this device wrote so far to system scope, then
+// store the sequence number into the peers' flag words.
+__global__ void signal_kernel(PeerTable peers, int world, int rank, int channel, uint32_t seq) {
+    const int q = threadIdx.x;
+    __threadfence_system();
+    if (q < world && q != rank)
+        __hip_atomic_store(peers.flags[q] + channel * kMaxWorld + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// spin until *flag >= seq (wrap-safe signed difference) or the wall clock (100 MHz) runs out
+__device__ __forceinline__ bool wait_flag(const uint32_t* flag, uint32_t seq, long long timeout_ticks, int* err) {
+    const long long t0 = wall_clock64();
+    while (true) {
+        const uint32_t v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(v - seq) >= 0) return true;
+        if (wall_clock64() - t0 > timeout_ticks) {
+            *err = 1;
+            __threadfence_system();
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+__global__ void wait_kernel(const uint32_t* flag, uint32_t seq, long long timeout_ticks, int* err) {
+    if (threadIdx.x == 0) wait_flag(flag, seq, timeout_ticks, err);
+}
+
+// Copy-kernel pulls: block b serves peer slot b / kPullBlocksPerPeer (the peers other than `rank`, in order).
+__global__ __launch_bounds__(kPullThreads) void pull_kernel(PeerTable peers, const uint32_t* my_flags, int world, int rank,
+                                                            int channel, uint32_t seq, size_t slot_off, size_t bytes,
+                                                            char* full, long long timeout_ticks, int* err) {
+    const int pi = blockIdx.x / kPullBlocksPerPeer;         // 0 .. world-2
+    const int sub = blockIdx.x - pi * kPullBlocksPerPeer;
+    const int q = pi < rank ? pi : pi + 1;
+    __shared__ int ok;
+    if (threadIdx.x == 0) ok = wait_flag(my_flags + channel * kMaxWorld + q, seq, timeout_ticks, err) ? 1 : 0;
+    __syncthreads();
+    if (!ok) return;
+    // the acquire above ran on one wave; make sure no stale line of the peer's slot (read two steps ago) is
+    // served from this XCD's caches to the other waves
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    const u32x4* __restrict__ s = reinterpret_cast<const u32x4*>(peers.data[q] + slot_off);
+    u32x4* __restrict__ d = reinterpret_cast<u32x4*>(full + (size_t)q * bytes);
+    const size_t n16 = bytes / 16;
+    const size_t stride = (size_t)kPullBlocksPerPeer * kPullThreads;
+    size_t i = (size_t)sub * kPullThreads + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {  // 4 independent 16-B loads in flight per lane
+        const u32x4 a = __builtin_nontemporal_load(s + i);
+        const u32x4 b = __builtin_nontemporal_load(s + i + stride);
+        const u32x4 c = __builtin_nontemporal_load(s + i + 2 * stride);
+        const u32x4 e = __builtin_nontemporal_load(s + i + 3 * stride);
+        d[i] = a;
+        d[i + stride] = b;
+        d[i + 2 * stride] = c;
+        d[i + 3 * stride] = e;
+    }
+    for (; i < n16; i += stride) d[i] = __builtin_nontemporal_load(s + i);
+    // tail bytes (shards are multiples of 4 bytes)
+    if (sub == 0) {
+        const size_t done = n16 * 16;
+        for (size_t j = done + threadIdx.x * 4; j < bytes; j += kPullThreads * 4)
+            *reinterpret_cast<uint32_t*>(full + (size_t)q * bytes + j) =
+                *reinterpret_cast<const uint32_t*>(peers.data[q] + slot_off + j);
+    }
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------------
+
+struct h2gcn_xchg {
+    int world = 1, rank = 0, n_channels = 1, mode = 0, device = 0;
+    size_t slot_bytes = 0;
+    long long timeout_ticks = 0;
+    char* data = nullptr;       // exported: n_channels * 2 slots
+    uint32_t* flags = nullptr;  // exported: [kMaxChannels][kMaxWorld] arrival counters, written by the peers
+    int* err = nullptr;         // host-mapped: set by a wait that gave up
+    bool connected = false;
+    PeerTable peers;
+    std::vector<void*> opened;          // pointers to close with hipIpcCloseMemHandle
+    std::vector<hipStream_t> streams;   // [world]; entry `rank` is the copy-kernel stream
+    std::vector<hipEvent_t> fence;      // [n_channels]
+    std::vector<hipEvent_t> pulled;     // [n_channels * world]
+    std::vector<char> pulled_valid;     // event has been recorded at least once
+    std::vector<uint32_t> seq;          // [n_channels]
+    std::vector<char> open_channel;     // begin without end
+};
+
+namespace {
+
+void release(h2gcn_xchg* x) {
+    if (!x) return;
+    for (hipStream_t s : x->streams)
+        if (s) (void)hipStreamSynchronize(s);
+    for (void* p : x->opened) (void)hipIpcCloseMemHandle(p);
+    for (hipEvent_t e : x->fence)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : x->pulled)
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t s : x->streams)
+        if (s) (void)hipStreamDestroy(s);
+    if (x->data) (void)hipFree(x->data);
+    if (x->flags) (void)hipFree(x->flags);
+    if (x->err) (void)hipHostFree(x->err);
+    delete x;
+}
+
+}  // namespace
+
+extern "C" {
+
+int h2gcn_xchg_create(int world, int rank, int n_channels, size_t slot_bytes, int mode, int timeout_ms,
+                      h2gcn_xchg_t** out) {
+    try {
+        if (!out) return fail(H2GCN_ERR_INVALID_ARGUMENT, "out is NULL");
+        *out = nullptr;
+        if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad rank %d / world %d (max %d)", rank, world, kMaxWorld);
+        if (n_channels < 1 || n_channels > kMaxChannels)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "n_channels = %d, supported 1..%d", n_channels, kMaxChannels);
+        if (mode != H2GCN_XCHG_COPY_ENGINE && mode != H2GCN_XCHG_COPY_KERNEL)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "unknown exchange mode %d", mode);
+        if (slot_bytes == 0 || slot_bytes % 4 != 0)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "slot_bytes = %zu must be a positive multiple of 4", slot_bytes);
+        h2gcn_xchg* x = new h2gcn_xchg();
+        struct Guard {
+            h2gcn_xchg* p;
+            ~Guard() { release(p); }
+        } guard{x};
+        x->world = world;
+        x->rank = rank;
+        x->n_channels = n_channels;
+        x->mode = mode;
+        x->slot_bytes = (slot_bytes + 255) / 256 * 256;  // keep every slot 256-B aligned
+        x->timeout_ticks = (long long)(timeout_ms > 0 ? timeout_ms : 10000) * 100000LL;  // wall_clock64: 100 MHz
+        memset(&x->peers, 0, sizeof(x->peers));
+        H2GCN_HIP_TRY(hipGetDevice(&x->device));
+        H2GCN_HIP_TRY(hipMalloc((void**)&x->data, x->slot_bytes * 2 * (size_t)n_channels));
+        H2GCN_HIP_TRY(hipMemset(x->data, 0, x->slot_bytes * 2 * (size_t)n_channels));
+        // arrival counters: fine-grained (uncached) device memory so that a store arriving over xGMI is seen by
+        // a spinning wave without any cache maintenance
+        const size_t flag_bytes = sizeof(uint32_t) * kMaxChannels * kMaxWorld;
+        hipError_t fe = hipExtMallocWithFlags((void**)&x->flags, flag_bytes, hipDeviceMallocUncached);
+        if (fe != hipSuccess) {
+            (void)hipGetLastError();
+            fe = hipExtMallocWithFlags((void**)&x->flags, flag_bytes, hipDeviceMallocFinegrained);
+        }
+        if (fe != hipSuccess) {
+            (void)hipGetLastError();
+            H2GCN_HIP_TRY(hipMalloc((void**)&x->flags, flag_bytes));
+        }
+        H2GCN_HIP_TRY(hipMemset(x->flags, 0, flag_bytes));
+        H2GCN_HIP_TRY(hipHostMalloc((void**)&x->err, sizeof(int), hipHostMallocMapped));
+        *x->err = 0;
+        H2GCN_HIP_TRY(hipDeviceSynchronize());
+        int lo = 0, hi = 0;
+        H2GCN_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
+        x->streams.assign(world, nullptr);
+        for (int q = 0; q < world; ++q) {
+            if (mode == H2GCN_XCHG_COPY_KERNEL && q != rank) continue;
+            if (mode == H2GCN_XCHG_COPY_ENGINE && q == rank) continue;
+            H2GCN_HIP_TRY(hipStreamCreateWithPriority(&x->streams[q], hipStreamNonBlocking, hi));
+        }
+        x->fence.assign(n_channels, nullptr);
+        for (auto& e : x->fence) H2GCN_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        x->pulled.assign((size_t)n_channels * world, nullptr);
+        for (auto& e : x->pulled) H2GCN_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        x->pulled_valid.assign((size_t)n_channels * world, 0);
+        x->seq.assign(n_channels, 0);
+        x->open_channel.assign(n_channels, 0);
+        x->peers.data[rank] = x->data;
+        x->peers.flags[rank] = x->flags;
+        x->connected = (world == 1);
+        guard.p = nullptr;
+        *out = x;
+        return H2GCN_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(H2GCN_ERR_OUT_OF_MEMORY, "host allocation failed in xchg_create");
+    } catch (...) {
+        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in xchg_create");
+    }
+}
+
+int h2gcn_xchg_export(const h2gcn_xchg_t* x, void* blob_out) {
+    if (!x || !blob_out) return fail(H2GCN_ERR_INVALID_ARGUMENT, "NULL argument");
+    Blob b;
+    memset(&b, 0, sizeof(b));
+    H2GCN_HIP_TRY(hipIpcGetMemHandle(&b.data, x->data));
+    H2GCN_HIP_TRY(hipIpcGetMemHandle(&b.flags, x->flags));
+    b.slot_bytes = x->slot_bytes;
+    b.world = x->world;
+    b.rank = x->rank;
+    b.n_channels = x->n_channels;
+    b.device = x->device;
+    b.pid = (int64_t)getpid();
+    b.magic = kMagic;
+    memset(blob_out, 0, H2GCN_XCHG_BLOB_BYTES);
+    memcpy(blob_out, &b, sizeof(b));
+    return H2GCN_OK;
+}
+
+int h2gcn_xchg_connect(h2gcn_xchg_t* x, const void* blobs) {
+    try {
+        if (!x || !blobs) return fail(H2GCN_ERR_INVALID_ARGUMENT, "NULL argument");
+        if (x->connected) return x->world == 1 ? H2GCN_OK : fail(H2GCN_ERR_INVALID_ARGUMENT, "already connected");
+        for (int q = 0; q < x->world; ++q) {
+            if (q == x->rank) continue;
+            Blob b;
+            memcpy(&b, (const char*)blobs + (size_t)q * H2GCN_XCHG_BLOB_BYTES, sizeof(b));
+            if (b.magic != kMagic || b.rank != q || b.world != x->world || b.n_channels != x->n_channels ||
+                b.slot_bytes != x->slot_bytes)
+                return fail(H2GCN_ERR_INVALID_ARGUMENT, "blob %d does not describe a matching exchange (rank %d, world %d, "
+                            "channels %d, slot %llu)", q, b.rank, b.world, b.n_channels, (unsigned long long)b.slot_bytes);
+            if (b.pid == (int64_t)getpid())
+                return fail(H2GCN_ERR_INVALID_ARGUMENT, "rank %d lives in this process: IPC handles can only be opened by "
+                            "other processes (one rank per process)", q);
+            void* pd = nullptr;
+            void* pf = nullptr;
+            H2GCN_HIP_TRY(hipIpcOpenMemHandle(&pd, b.data, hipIpcMemLazyEnablePeerAccess));
+            x->opened.push_back(pd);
+            H2GCN_HIP_TRY(hipIpcOpenMemHandle(&pf, b.flags, hipIpcMemLazyEnablePeerAccess));
+            x->opened.push_back(pf);
+            x->peers.data[q] = (char*)pd;
+            x->peers.flags[q] = (uint32_t*)pf;
+        }
+        x->connected = true;
+        return H2GCN_OK;
+    } catch (...) {
+        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in xchg_connect");
+    }
+}
+
+int h2gcn_xchg_allgather_begin(h2gcn_xchg_t* x, int channel, const float* src, int64_t ld_src, int64_t rows,
+                               int64_t rows_per_rank, int32_t width, float* full, void* stream_v) {
+    try {
+        if (!x) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is NULL");
+        if (!x->connected) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is not connected");
+        if (channel < 0 || channel >= x->n_channels) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d outside 0..%d", channel, x->n_channels - 1);
+        if (x->open_channel[channel]) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d: begin without a matching end", channel);
+        if (width < 1 || rows < 0 || rows > rows_per_rank || ld_src < width || (!src && rows > 0) || !full)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad shard (rows %lld of %lld, width %d, ld %lld)", (long long)rows,
+                        (long long)rows_per_rank, width, (long long)ld_src);
+        const size_t bytes = (size_t)rows_per_rank * (size_t)width * 4;
+        if (bytes > x->slot_bytes) return fail(H2GCN_ERR_INVALID_ARGUMENT, "shard of %zu bytes exceeds the slot (%zu)", bytes, x->slot_bytes);
+        int cur = -1;
+        H2GCN_HIP_TRY(hipGetDevice(&cur));
+        if (cur != x->device) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange lives on device %d, current device is %d", x->device, cur);
+        hipStream_t stream = (hipStream_t)stream_v;
+        const uint32_t seq = ++x->seq[channel];
+        const size_t slot_off = ((size_t)channel * 2 + (seq & 1u)) * x->slot_bytes;
+        float* own = full + (size_t)x->rank * (size_t)rows_per_rank * width;
+
+        // everything enqueued on `stream` so far (e.g. the SpMM still reading `full`) precedes the pulls
+        H2GCN_HIP_TRY(hipEventRecord(x->fence[channel], stream));
+        // the slot is free once this channel's previous pulls are done (see the protocol note above)
+        for (int q = 0; q < x->world; ++q)
+            if (x->pulled_valid[(size_t)channel * x->world + q])
+                H2GCN_HIP_TRY(hipStreamWaitEvent(stream, x->pulled[(size_t)channel * x->world + q], 0));
+        if (rows_per_rank > 0) {
+            const bool vec4 = width % 4 == 0 && ld_src % 4 == 0 && ((uintptr_t)src & 15u) == 0 && ((uintptr_t)own & 15u) == 0;
+            const int64_t total = rows_per_rank * (vec4 ? width / 4 : width);
+            const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+            if (vec4)
+                hipLaunchKernelGGL(stage_kernel<true>, dim3(blocks), dim3(256), 0, stream, src, ld_src, rows, rows_per_rank,
+                                   (int)width, (float*)(x->data + slot_off), own);
+            else
+                hipLaunchKernelGGL(stage_kernel<false>, dim3(blocks), dim3(256), 0, stream, src, ld_src, rows, rows_per_rank,
+                                   (int)width, (float*)(x->data + slot_off), own);
+            H2GCN_HIP_TRY(hipGetLastError());
+        }
+        if (x->world > 1) {
+            hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, stream, x->peers, x->world, x->rank, channel, seq);
+            H2GCN_HIP_TRY(hipGetLastError());
+        }
+        x->open_channel[channel] = 1;
+        if (x->world == 1 || bytes == 0) return H2GCN_OK;
+
+        if (x->mode == H2GCN_XCHG_COPY_KERNEL) {
+            hipStream_t cs = x->streams[x->rank];
+            H2GCN_HIP_TRY(hipStreamWaitEvent(cs, x->fence[channel], 0));
+            hipLaunchKernelGGL(pull_kernel, dim3((x->world - 1) * kPullBlocksPerPeer), dim3(kPullThreads), 0, cs, x->peers,
+                               (const uint32_t*)x->flags, x->world, x->rank, channel, seq, slot_off, bytes, (char*)full,
+                               x->timeout_ticks, x->err);
+            H2GCN_HIP_TRY(hipGetLastError());
+            const size_t ei = (size_t)channel * x->world + x->rank;
+            H2GCN_HIP_TRY(hipEventRecord(x->pulled[ei], cs));
+            x->pulled_valid[ei] = 1;
+        } else {
+            for (int shift = 1; shift < x->world; ++shift) {
+                const int q = (x->rank + shift) % x->world;  // start with a different peer on every rank
+                hipStream_t ps = x->streams[q];
+                H2GCN_HIP_TRY(hipStreamWaitEvent(ps, x->fence[channel], 0));
+                hipLaunchKernelGGL(wait_kernel, dim3(1), dim3(64), 0, ps, (const uint32_t*)(x->flags + channel * kMaxWorld + q),
+                                   seq, x->timeout_ticks, x->err);
+                H2GCN_HIP_TRY(hipGetLastError());
+                H2GCN_HIP_TRY(hipMemcpyAsync((char*)full + (size_t)q * bytes, x->peers.data[q] + slot_off, bytes,
+                                             hipMemcpyDeviceToDevice, ps));
+                const size_t ei = (size_t)channel * x->world + q;
+                H2GCN_HIP_TRY(hipEventRecord(x->pulled[ei], ps));
+                x->pulled_valid[ei] = 1;
+            }
+        }
+        return H2GCN_OK;
+    } catch (...) {
+        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in xchg_allgather_begin");
+    }
+}
+
+int h2gcn_xchg_allgather_end(h2gcn_xchg_t* x, int channel, void* stream_v) {
+    if (!x) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is NULL");
+    if (channel < 0 || channel >= x->n_channels) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d outside 0..%d", channel, x->n_channels - 1);
+    if (!x->open_channel[channel]) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d: end without begin", channel);
+    hipStream_t stream = (hipStream_t)stream_v;
+    for (int q = 0; q < x->world; ++q)
+        if (x->pulled_valid[(size_t)channel * x->world + q])
+            H2GCN_HIP_TRY(hipStreamWaitEvent(stream, x->pulled[(size_t)channel * x->world + q], 0));
+    x->open_channel[channel] = 0;
+    return H2GCN_OK;
+}
+
+int h2gcn_xchg_status(const h2gcn_xchg_t* x) {
+    if (!x) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is NULL");
+    if (*(volatile int*)x->err)
+        return fail(H2GCN_ERR_EXCHANGE_TIMEOUT, "rank %d: a peer's shard did not arrive in time (peer missing, or ranks "
+                    "issuing different exchange sequences)", x->rank);
+    return H2GCN_OK;
+}
+
+void h2gcn_xchg_destroy(h2gcn_xchg_t* x) { release(x); }
+
+}  // extern "C"

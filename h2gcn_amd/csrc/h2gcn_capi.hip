@@ -22,7 +22,9 @@
 #include "h2gcn_hip.h"
 #include "spmm_kernels.hip.h"
 
-namespace {
+#include "capi_internal.h"
+
+namespace h2gcn {
 
 thread_local std::string g_last_error;
 
@@ -36,13 +38,12 @@ int fail(h2gcn_status st, const char* fmt, ...) {
     return (int)st;
 }
 
-#define H2GCN_HIP_TRY(expr)                                                                          \
-    do {                                                                                             \
-        hipError_t _e = (expr);                                                                      \
-        if (_e != hipSuccess)                                                                        \
-            return fail(_e == hipErrorOutOfMemory ? H2GCN_ERR_OUT_OF_MEMORY : H2GCN_ERR_HIP,         \
-                        "%s failed: %s", #expr, hipGetErrorString(_e));                              \
-    } while (0)
+}  // namespace h2gcn
+
+namespace {
+
+using h2gcn::fail;
+using h2gcn::g_last_error;
 
 struct DeviceBuf {
     void* p = nullptr;

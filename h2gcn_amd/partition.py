@@ -20,16 +20,20 @@ import torch
 import torch.distributed as dist
 
 
-def init_rccl_process_group(device: torch.device) -> None:
+def init_rccl_process_group(device: torch.device, timeout_s: Optional[float] = None) -> None:
     """``torch.distributed`` over RCCL with a HIGH-PRIORITY communication stream: the exchange kernels must be
     scheduled promptly while a 150k-workgroup SpMM grid saturates every CU, otherwise the pipelining of
-    :class:`PipelinedHopAggregation` degenerates into serial execution."""
+    :class:`PipelinedHopAggregation` degenerates into serial execution.  ``timeout_s`` bounds every collective so
+    that a rank that failed leaves its peers with an error instead of a hang."""
+    import datetime
+
+    kw = {} if timeout_s is None else {"timeout": datetime.timedelta(seconds=float(timeout_s))}
     try:
         opts = dist.ProcessGroupNCCL.Options()
         opts.is_high_priority_stream = True
-        dist.init_process_group("nccl", device_id=device, pg_options=opts)
+        dist.init_process_group("nccl", device_id=device, pg_options=opts, **kw)
     except (AttributeError, TypeError):  # older torch: no options object
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl", device_id=device, **kw)
 
 
 def block_bounds(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -89,6 +93,101 @@ def shard_rows_scipy(mats, world_size: int, rank: int):
     return out
 
 
+class IpcExchange:
+    """All-gather of row shards through IPC-exported device buffers (``h2gcn_xchg_*`` of ``libh2gcn_hip.so``): each
+    rank stages its shard into an exported slot, flags its peers over xGMI, and pulls the peers' shards with
+    copy-engine transfers on one stream per peer (``mode="engine"``: no CU is taken from the SpMM, every
+    point-to-point link carries its own transfer) or one small copy kernel (``mode="kernel"``).  An alternative to
+    ``ncclAllGather`` that needs only a bootstrap channel (``all_gather_object`` of 192-byte handles, any backend)
+    -- and, unlike RCCL, also runs with several ranks on ONE GPU, which is how the GPU suite tests it.
+
+    ``begin(channel, x_shard, full)`` returns at once (everything is enqueued device-side); ``end(channel)`` makes
+    the current stream wait for the shards.  ``check()`` raises if any device-side wait ever timed out."""
+
+    def __init__(self, n_channels: int, slot_bytes: int, device, group: Optional[dist.ProcessGroup] = None,
+                 mode: str = "engine", timeout_ms: int = 10000):
+        import ctypes as C
+
+        from . import _capi
+        if mode not in ("engine", "kernel"):
+            raise ValueError(f"unknown IPC exchange mode {mode!r}")
+        self._C, self._capi = C, _capi
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.device = torch.device(device)
+        self.mode = mode
+        self._handle = C.c_void_p()
+        L = _capi.lib()
+        # Collectively safe: a rank whose local set-up fails still takes part in the handle exchange (sending None),
+        # so its peers raise instead of waiting for it.
+        blob, err = None, None
+        with torch.cuda.device(self.device):
+            try:
+                _capi.check(L.h2gcn_xchg_create(self.world, self.rank, int(n_channels), int(slot_bytes),
+                                                _capi.XCHG_COPY_ENGINE if mode == "engine" else _capi.XCHG_COPY_KERNEL,
+                                                int(timeout_ms), C.byref(self._handle)))
+                buf = C.create_string_buffer(_capi.XCHG_BLOB_BYTES)
+                _capi.check(L.h2gcn_xchg_export(self._handle, buf))
+                blob = bytes(buf.raw)
+            except Exception as e:  # noqa: BLE001 -- reported below, after the collective
+                err = e
+            if self.world > 1:
+                blobs = [None] * self.world
+                dist.all_gather_object(blobs, blob, group=group)
+                if err is None and all(b is not None for b in blobs):
+                    try:
+                        _capi.check(L.h2gcn_xchg_connect(self._handle, b"".join(blobs)))
+                    except Exception as e:  # noqa: BLE001
+                        err = e
+                oks = [None] * self.world
+                dist.all_gather_object(oks, err is None and all(b is not None for b in blobs), group=group)
+                if not all(oks):
+                    self._destroy_local()
+                    raise RuntimeError(f"IPC exchange unavailable (ranks ok: {oks})" + (f": {err}" if err else ""))
+            elif err is not None:
+                raise err
+
+    def _destroy_local(self) -> None:
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            self._capi.lib().h2gcn_xchg_destroy(h)
+            self._handle = self._C.c_void_p()
+
+    def begin(self, channel: int, x_shard: torch.Tensor, full: torch.Tensor, rows_per_rank: int) -> None:
+        """Start gathering ``x_shard`` ([rows <= rows_per_rank, w], last dim contiguous) into ``full``
+        ([world * rows_per_rank, w] contiguous)."""
+        if x_shard.dim() != 2 or x_shard.dtype != torch.float32 or (x_shard.shape[1] > 1 and x_shard.stride(1) != 1):
+            raise ValueError("shard must be a float32 [rows, w] view with a contiguous last dimension")
+        w = int(x_shard.shape[1])
+        if tuple(full.shape) != (self.world * rows_per_rank, w) or not full.is_contiguous() or full.dtype != torch.float32:
+            raise ValueError(f"full must be a contiguous float32 [{self.world * rows_per_rank}, {w}] buffer")
+        C = self._C
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self._capi.check(self._capi.lib().h2gcn_xchg_allgather_begin(
+                self._handle, int(channel), C.c_void_p(x_shard.data_ptr()), x_shard.stride(0) if x_shard.shape[0] > 0 else w,
+                int(x_shard.shape[0]), int(rows_per_rank), w, C.c_void_p(full.data_ptr()), C.c_void_p(stream)))
+
+    def end(self, channel: int) -> None:
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self._capi.check(self._capi.lib().h2gcn_xchg_allgather_end(self._handle, int(channel), self._C.c_void_p(stream)))
+
+    def check(self) -> None:
+        self._capi.check(self._capi.lib().h2gcn_xchg_status(self._handle))
+
+    def close(self) -> None:
+        """Collective: synchronises, makes sure no peer is still pulling from this rank, then frees the buffers."""
+        h = getattr(self, "_handle", None)
+        if h is None or not h.value:
+            return
+        torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            dist.barrier(group=self.group)
+        self._destroy_local()
+
+
 class PipelinedHopAggregation:
     """One layer's exchange + aggregation with the all-gather hidden behind the SpMM.
 
@@ -110,10 +209,11 @@ class PipelinedHopAggregation:
         """``n_chunks``: number of equal feature chunks, or an explicit list of chunk widths summing to ``d``
         (e.g. ``[32, 32, 64]``: a narrow first chunk shortens the un-overlapped head of the exchange, wider later
         chunks keep the SpMM efficient)."""
-        if exchange not in ("allgather", "p2p"):
+        if exchange not in ("allgather", "p2p", "ipc_engine", "ipc_kernel"):
             raise ValueError(f"unknown exchange {exchange!r}")
-        self._gather = _all_gather_rows if exchange == "allgather" else _all_gather_rows_p2p
+        self._gather = _all_gather_rows_p2p if exchange == "p2p" else _all_gather_rows
         self.exchange = exchange
+        self.ipc = None
         if isinstance(n_chunks, (list, tuple)):
             widths = [int(w) for w in n_chunks]
             if sum(widths) != d or min(widths) < 1:
@@ -143,8 +243,31 @@ class PipelinedHopAggregation:
             if self.use_streams:
                 self.staged = [torch.cuda.Event() for _ in range(self.C)]
                 self.ready = [torch.cuda.Event() for _ in range(self.C)]
+            if exchange.startswith("ipc_"):
+                if not self.use_streams:
+                    raise ValueError("the IPC exchange needs GPU buffers")
+                self.ipc = IpcExchange(self.C, self.per * max(widths) * 4, device, group, mode=exchange[4:])
         #: set to a list to have (start, end) timing-event pairs appended around every SpMM launch
         self.kernel_events = None
+
+    def close(self) -> None:
+        """Collective (when the IPC exchange is in use): release the exported buffers."""
+        if self.ipc is not None:
+            self.ipc.close()
+            self.ipc = None
+
+    def exchange_only(self) -> None:
+        """The step's exchange without the SpMM (diagnostics): every chunk of the last staged shard again."""
+        if self.world == 1:
+            return
+        if self.ipc is not None:
+            for c in range(self.C):
+                self.ipc.begin(c, self.send[c], self.full[c], self.per)
+            for c in range(self.C):
+                self.ipc.end(c)
+        else:
+            for c in range(self.C):
+                self._gather(self.full[c], self.send[c], self.group)
 
     def _spmm(self, x, out):
         if self.kernel_events is None or not self.use_streams:
@@ -172,6 +295,15 @@ class PipelinedHopAggregation:
             for c in range(self.C):
                 self.send[c][:n_local].copy_(x_local[:, cols[c]])
                 self._gather(self.full[c], self.send[c], self.group)
+                self._spmm(self.full[c][: self.n], out[:, :, cols[c]])
+            return out
+        if self.ipc is not None:
+            # staging + notification of every chunk first (device-side order matters, see exchange.hip), pulls run on
+            # the library's own streams; the SpMM of chunk c only waits for chunk c's shards
+            for c in range(self.C):
+                self.ipc.begin(c, x_local[:, cols[c]], self.full[c], self.per)
+            for c in range(self.C):
+                self.ipc.end(c)
                 self._spmm(self.full[c][: self.n], out[:, :, cols[c]])
             return out
         main = torch.cuda.current_stream(self.device)

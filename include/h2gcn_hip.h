@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define H2GCN_ABI_VERSION 1
+#define H2GCN_ABI_VERSION 2
 #define H2GCN_MAX_HOPS 8
 
 typedef enum h2gcn_status {
@@ -48,7 +48,8 @@ typedef enum h2gcn_status {
     H2GCN_ERR_OUT_OF_MEMORY = -3,    /* host or device allocation failed                                  */
     H2GCN_ERR_BAD_INDEX = -4,        /* rowptr not monotone / colidx out of range (TF: InvalidArgument)   */
     H2GCN_ERR_NO_TRANSPOSE = -5,     /* adjoint launch on a plan created without H2GCN_PLAN_BUILD_TRANSPOSE */
-    H2GCN_ERR_INTERNAL = -6
+    H2GCN_ERR_INTERNAL = -6,
+    H2GCN_ERR_EXCHANGE_TIMEOUT = -7  /* a peer's shard did not arrive within the exchange's time limit      */
 } h2gcn_status;
 
 /* flags for h2gcn_plan_opts.flags */
@@ -149,6 +150,61 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
  */
 int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* dY_dev, int64_t ldg_row,
                           int64_t ldg_hop, int32_t d, float* dX_dev, int64_t ldx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Row-shard exchange between the GPUs of one node (no counterpart in the reference: it is single-process,
+ * single-device -- SURVEY.md 8(e) adds the row partition).  Before a hop aggregation every rank needs the whole
+ * embedding X[N, d] while it owns only X[rows_p, :]; this object performs that all-gather WITHOUT a collective
+ * library: every rank stages its shard into a buffer it has exported with hipIpcGetMemHandle, tells its peers
+ * (a sequence number stored into their flag words over xGMI), and pulls the peers' shards straight out of their
+ * exported buffers -- either with copy-engine transfers (hipMemcpyAsync device-to-device, one stream per peer:
+ * no CU is used, every point-to-point xGMI link carries its own transfer) or with one small copy kernel.
+ * It is an alternative to ncclAllGather behind the same Python interface (h2gcn_amd/partition.py); which is
+ * faster is a property of the node and is measured, not assumed (bench.py).
+ *
+ * Life cycle (one object per rank, all ranks make the same calls in the same order):
+ *   create -> export (blob) -> [blobs of all ranks are exchanged by the caller, e.g. torch.distributed
+ *   all_gather_object] -> connect -> { allgather_begin(channel) ... allgather_end(channel) }* -> [caller
+ *   barrier] -> destroy.
+ * A "channel" is an independent double-buffered send slot with its own sequence counter (the feature-chunk
+ * pipeline uses one channel per chunk).  Nothing here blocks the host; a peer that never posts makes the waiting
+ * GPU give up after `timeout_ms` and the failure is reported by h2gcn_xchg_status().
+ */
+typedef struct h2gcn_xchg h2gcn_xchg_t;
+
+#define H2GCN_XCHG_BLOB_BYTES 192          /* size of the opaque blob h2gcn_xchg_export writes                  */
+#define H2GCN_XCHG_COPY_ENGINE 0           /* mode: pulls are hipMemcpyAsync D2D on one stream per peer (SDMA)  */
+#define H2GCN_XCHG_COPY_KERNEL 1           /* mode: pulls are one copy kernel reading the peers' memory         */
+
+/*   world, rank      number of ranks / this rank (one rank per process; peers must be other processes)
+ *   n_channels       independent slots (1..64)
+ *   slot_bytes       capacity of one slot = the largest shard (rows_per_rank * width * 4) posted on a channel
+ *   mode             H2GCN_XCHG_COPY_ENGINE or H2GCN_XCHG_COPY_KERNEL
+ *   timeout_ms       how long a GPU waits for a peer's shard before giving up (0 = default 10000)            */
+int h2gcn_xchg_create(int world, int rank, int n_channels, size_t slot_bytes, int mode, int timeout_ms,
+                      h2gcn_xchg_t** out);
+/* Writes H2GCN_XCHG_BLOB_BYTES bytes describing this rank's exported buffers. */
+int h2gcn_xchg_export(const h2gcn_xchg_t* x, void* blob_out);
+/* `blobs` = the world blobs in rank order (world * H2GCN_XCHG_BLOB_BYTES bytes); opens every peer's buffers. */
+int h2gcn_xchg_connect(h2gcn_xchg_t* x, const void* blobs);
+/*
+ * Start the all-gather of one shard on `channel`:
+ *   src_dev   this rank's rows, fp32 [rows, width] with row stride ld_src (elements); rows <= rows_per_rank
+ *   full_dev  destination, fp32 [world * rows_per_rank, width] contiguous; rank q's shard lands in rows
+ *             [q*rows_per_rank, (q+1)*rows_per_rank) (rows beyond a short last shard are zero)
+ *   stream    the stream that produced src_dev; the staging copy and the notification are ordered on it, and
+ *             the pulls (internal streams) start only after everything enqueued on it so far -- so a kernel that
+ *             is still reading full_dev from the previous use is safe.
+ * Returns immediately.  Exactly one allgather_end must follow before the next begin on the same channel. */
+int h2gcn_xchg_allgather_begin(h2gcn_xchg_t* x, int channel, const float* src_dev, int64_t ld_src, int64_t rows,
+                               int64_t rows_per_rank, int32_t width, float* full_dev, void* stream);
+/* Make `stream` wait (device-side, no host block) until every shard of `channel` has landed in full_dev. */
+int h2gcn_xchg_allgather_end(h2gcn_xchg_t* x, int channel, void* stream);
+/* H2GCN_OK, or H2GCN_ERR_EXCHANGE_TIMEOUT if any wait on this object has ever given up (results are then
+ * undefined).  Does not synchronise: call after the streams involved have been synchronised. */
+int h2gcn_xchg_status(const h2gcn_xchg_t* x);
+/* Release everything.  The caller must make sure (barrier) that no peer is still pulling from this rank. */
+void h2gcn_xchg_destroy(h2gcn_xchg_t* x);
 
 #ifdef __cplusplus
 }

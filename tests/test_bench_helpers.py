@@ -22,7 +22,7 @@ def test_algorithmic_and_compulsory_bytes():
     assert b.algorithmic_bytes(nnz, n, d, 2) == want == 127274403896
     assert b.compulsory_bytes(nnz, n, n, d, 2) == sum(z * 8 + (n + 1) * 8 for z in nnz) + n * d * 4 + n * 2 * d * 4
     assert b.HBM_PEAK_GBPS == 8000.0
-    assert b.pmc_traffic("products", 128, 1, 0, 1) is not None       # committed PMC summary
+    assert b.pmc_traffic("products", 128, 1, 0, 1)["bytes_per_launch"] > 1e11   # committed PMC summary (+ its source)
     assert b.pmc_traffic("products", 128, 1, 0, 8) is None           # never profiled -> null, not a guess
 
 

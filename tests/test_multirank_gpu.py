@@ -32,7 +32,7 @@ degs = [synth.synth_degrees(n, 40 * n, s, n) for s in (1, 2)]
 csr = [synth.synth_hop_rows(degs[k], n, (1, 2)[k], r0, r1, dev) for k in range(2)]
 plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n, build_transpose=True)
 x_local = synth.synth_features(d, 3, r0, r1, dev).requires_grad_(True)
-layer = PipelinedHopAggregation(plan, n, d, chunks, dev)
+layer = PipelinedHopAggregation(plan, n, d, chunks, dev, exchange=os.environ["EXCHANGE"])
 for _ in range(3):                       # repeated steps: buffer reuse across steps must be race-free
     y = sharded_hop_spmm(layer, x_local)
 w = synth.synth_features(2 * d, 9, r0, r1, dev).view(r1 - r0, 2, d)
@@ -41,6 +41,9 @@ torch.cuda.synchronize()
 out = os.environ["OUT_DIR"]
 np.save(f"{out}/y{rank}.npy", y.detach().cpu().numpy())
 np.save(f"{out}/dx{rank}.npy", x_local.grad.cpu().numpy())
+if layer.ipc is not None:
+    layer.ipc.check()
+layer.close()
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -54,8 +57,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("chunks", [1, 4])
-def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, chunks):
+@pytest.mark.parametrize("exchange,chunks", [("allgather", 1), ("allgather", 4), ("ipc_engine", 1), ("ipc_engine", 4),
+                                             ("ipc_kernel", 1), ("ipc_kernel", 4)])
+def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, exchange, chunks):
     from h2gcn_amd import HopPlan, synth
     from h2gcn_amd.partition import PipelinedHopAggregation
 
@@ -63,7 +67,7 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, chunks):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OUT_DIR=str(tmp_path), CHUNKS=str(chunks), H2GCN_ROOT=str(ROOT))
+                   OUT_DIR=str(tmp_path), CHUNKS=str(chunks), EXCHANGE=exchange, H2GCN_ROOT=str(ROOT))
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
@@ -130,3 +134,154 @@ def test_row_partitioned_training_matches_single_process(tmp_path):
         assert abs(a[k] - b[k]) <= 2e-3, (k, a[k], b[k])
     for k in ("train_acc", "val_acc", "test_accuracy"):     # argmax flips of single nodes are allowed early on
         assert abs(a[k] - b[k]) <= 0.02, (k, a[k], b[k])
+
+
+IPC_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["H2GCN_ROOT"])
+from h2gcn_amd.partition import IpcExchange
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo")
+per, mode = 1000, os.environ["MODE"]
+rows = per if rank < world - 1 else per - 37            # short last shard -> zero padding
+widths = [64, 20, 3]                                     # float4 path, 16-B but narrow, scalar path
+xc = IpcExchange(len(widths), per * max(widths) * 4, dev, mode=mode, timeout_ms=20000)
+wide = torch.empty((rows, 200), device=dev)
+fulls = [torch.full((world * per, w), -7.0, device=dev) for w in widths]
+ok = True
+for step in range(6):                                    # slot reuse: both halves of the double buffer, 3 times
+    wide.copy_(torch.arange(rows * 200, device=dev, dtype=torch.float32).view(rows, 200) * (rank + 1) + step)
+    off = 0
+    for c, w in enumerate(widths):
+        xc.begin(c, wide[:, off:off + w], fulls[c], per)
+        off += w
+    off = 0
+    for c, w in enumerate(widths):
+        xc.end(c)
+        got = fulls[c].clone()                          # stream-ordered after end()
+        for q in range(world):
+            rq = per if q < world - 1 else per - 37
+            want = torch.arange(rq * 200, device=dev, dtype=torch.float32).view(rq, 200)[:, off:off + w] * (q + 1) + step
+            ok = ok and torch.equal(got[q * per:q * per + rq], want) and bool((got[q * per + rq:(q + 1) * per] == 0).all())
+        off += w
+torch.cuda.synchronize()
+xc.check()
+xc.close()
+dist.barrier()
+dist.destroy_process_group()
+assert ok
+print("IPC_OK")
+"""
+
+
+@pytest.mark.parametrize("mode", ["engine", "kernel"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_ipc_exchange_gathers_strided_shards(tmp_path, mode, world):
+    """h2gcn_xchg_* alone: strided column windows of a wider buffer, a short last shard, three widths (vector and
+    scalar staging), six rounds over the double-buffered slots -- several processes on the one GPU of the box."""
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MODE=mode, H2GCN_ROOT=str(ROOT))
+        procs.append(subprocess.Popen([sys.executable, "-c", IPC_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs) and all("IPC_OK" in o for o in outs), "\n".join(outs)
+
+
+def test_ipc_exchange_times_out_instead_of_hanging(tmp_path):
+    """A peer that never posts: the waiting GPU gives up after timeout_ms and status() reports it (no hang)."""
+    worker = r"""
+import os, sys, time
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["H2GCN_ROOT"])
+from h2gcn_amd.partition import IpcExchange
+from h2gcn_amd._capi import H2GCNError, ERR_EXCHANGE_TIMEOUT
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0); dev = torch.device("cuda", 0)
+dist.init_process_group("gloo")
+xc = IpcExchange(1, 4096, dev, mode=os.environ["MODE"], timeout_ms=500)
+full = torch.zeros((2 * 16, 8), device=dev)
+if rank == 0:                                  # rank 1 never posts
+    xc.begin(0, torch.ones((16, 8), device=dev), full, 16)
+    xc.end(0)
+    t = time.time(); torch.cuda.synchronize(); dt = time.time() - t
+    try:
+        xc.check(); print("NO_ERROR")
+    except H2GCNError as e:
+        print("TIMEOUT_OK" if e.status == ERR_EXCHANGE_TIMEOUT and dt < 30 else f"BAD {e.status} {dt}")
+else:
+    print("TIMEOUT_OK")
+xc.close()
+dist.barrier(); dist.destroy_process_group()
+"""
+    for mode in ("engine", "kernel"):
+        port = _free_port()
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       MODE=mode, H2GCN_ROOT=str(ROOT))
+            procs.append(subprocess.Popen([sys.executable, "-c", worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs) and all("TIMEOUT_OK" in o for o in outs), "\n".join(outs)
+
+
+def _run_bench(world, extra, tmp_path, env_extra=None):
+    """bench.py as real subprocesses: `world` ranks sharing the one GPU (gloo bootstrap), returns the parsed JSON line."""
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ)
+        if world > 1:
+            env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1")
+        else:
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--no-cpu-baseline",
+                                       "--no-probe"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=1500) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1].decode()[-3000:] for o in outs)
+    lines = [l for l in outs[0][0].decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, outs[0][0].decode()
+    for o in outs[1:]:
+        assert not [l for l in o[0].decode().splitlines() if l.startswith("{")]   # only rank 0 prints
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_branch_runs_and_matches_one_rank(tmp_path, world):
+    """bench.py's N > 1 branch end to end (calibration over every exchange x chunking, diagnostics, timed steps,
+    JSON line) on the arxiv shape, N ranks sharing the box's GPU; the N-rank result has the same bits as the 1-rank
+    result with the same chunking (order-independent checksum of Y)."""
+    out = _run_bench(world, ["--shape", "arxiv", "--steps", "3", "--warmup", "1"], tmp_path)
+    assert out["n_gpus"] == world and out["value"] > 0 and out["roofline"]["kernel_ms_max_over_ranks"] > 0
+    diag = out["config"]["diagnostics"]
+    cal = diag["calibration_ms_per_step"]
+    assert cal and all(v > 0 for v in cal.values())
+    for ex in ("allgather", "ipc_engine", "ipc_kernel"):          # all three exchange forms were timed
+        assert any(k.startswith(ex + "/") for k in cal), (cal, diag["rejected"])
+    assert diag["exchange_only_ms"] > 0 and diag["spmm_only_ms"] > 0
+    (tmp_path / f"line{world}.json").write_text(json.dumps(out))
+    prof = ROOT / "gpurun_out"
+    prof.mkdir(exist_ok=True)
+    (prof / f"bench_shared_gpu_arxiv_n{world}.json").write_text(json.dumps(out))
+    one = _run_bench(1, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--chunks", str(out["config"]["feature_chunks"])], tmp_path)
+    assert one["config"]["y_checksum"] == out["config"]["y_checksum"]
+    assert one["config"]["nnz_per_hop"] == out["config"]["nnz_per_hop"]
+
+
+def test_bench_two_ranks_products_shape(tmp_path):
+    """configs[4] at N = 2 on the shared GPU, one forced schedule per exchange family (the calibration sweep is
+    covered on the arxiv shape): runs, reports, and the IPC result has the bits of the RCCL-style result."""
+    sums = {}
+    for ex in ("allgather", "ipc_engine"):
+        out = _run_bench(2, ["--steps", "2", "--warmup", "1", "--exchange", ex, "--chunks", "2", "--no-adjoint"], tmp_path)
+        assert out["value"] > 0 and out["config"]["diagnostics"]["exchange"] == ex
+        sums[ex] = out["config"]["y_checksum"]
+        (ROOT / "gpurun_out" / f"bench_shared_gpu_products_n2_{ex}.json").write_text(json.dumps(out))
+    assert sums["allgather"] == sums["ipc_engine"]

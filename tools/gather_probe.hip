@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -45,7 +46,51 @@ double run(const float4* table, long n_rows, long n_waves, int gpw, float4* out)
     return (double)n_waves * gpw * LPR * 16.0 * reps / (ms * 1e-3) / 1e9;
 }
 
-int main() {
+__global__ __launch_bounds__(256) void copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const float __attribute__((ext_vector_type(4)))*>(src) + i),
+                                    reinterpret_cast<float __attribute__((ext_vector_type(4)))*>(dst) + i);
+}
+
+// plain stream copy of `bytes` (read + write counted): the achievable HBM rate of this box
+double run_copy(size_t bytes) {
+    float4 *a, *b; CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, bytes)); CHECK(hipMemset(a, 1, bytes)); CHECK(hipMemset(b, 0, bytes));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const size_t n = bytes / 16;
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(copy_kernel, dim3(256 * 32), dim3(256), 0, 0, a, b, n);
+    CHECK(hipEventRecord(e0));
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(copy_kernel, dim3(256 * 32), dim3(256), 0, 0, a, b, n);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    CHECK(hipFree(a)); CHECK(hipFree(b));
+    return 2.0 * bytes * reps / (ms * 1e-3) / 1e9;
+}
+
+// `gather_probe --point <table_MiB> <row_bytes>`: one gather point + the copy ceiling, as one JSON line (bench.py)
+int point(size_t table_mib, int row_bytes) {
+    const size_t bytes = table_mib << 20;
+    float4* table; CHECK(hipMalloc(&table, bytes)); CHECK(hipMemset(table, 0, bytes));
+    const long n_waves = 1 << 18; const int gpw = 512;
+    float4* out; CHECK(hipMalloc(&out, n_waves * 64 * sizeof(float4)));
+    double g = 0;
+    switch (row_bytes) {
+        case 64: g = run<4>(table, bytes / 64, n_waves, gpw, out); break;
+        case 128: g = run<8>(table, bytes / 128, n_waves, gpw, out); break;
+        case 256: g = run<16>(table, bytes / 256, n_waves, gpw, out); break;
+        case 512: g = run<32>(table, bytes / 512, n_waves, gpw, out); break;
+        default: g = run<64>(table, bytes / 1024, n_waves, gpw, out); row_bytes = 1024; break;
+    }
+    CHECK(hipFree(table)); CHECK(hipFree(out));
+    const double c = run_copy(2ull << 30);
+    printf("{\"table_MiB\": %zu, \"row_bytes\": %d, \"gather_GBps\": %.1f, \"copy_GBps\": %.1f, "
+           "\"what\": \"tools/gather_probe: random row gathers out of a table of this size (8 x 16-B loads in flight per lane); "
+           "copy = nontemporal stream copy of 2 GiB, read+write bytes\"}\n", table_mib, row_bytes, g, c);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc == 4 && !strcmp(argv[1], "--point")) return point((size_t)atol(argv[2]), atoi(argv[3]));
     const size_t max_bytes = 8ull << 30;
     float4* table; CHECK(hipMalloc(&table, max_bytes)); CHECK(hipMemset(table, 0, max_bytes));
     const long n_waves = 1 << 18; const int gpw = 512;
