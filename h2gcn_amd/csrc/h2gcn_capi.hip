@@ -177,12 +177,22 @@ int get_long_list(const h2gcn_plan* plan, bool adjoint, uint32_t mask, const int
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Column-slice width of the EXACT kernels: the largest fast width that divides d, capped so that the gather
-// working set of one slice (n_src_rows * slice * 4 B) is friendlier to the 256 MiB Infinity Cache when the whole
-// operand is far beyond it.  `forced` > 0 (plan option) overrides the heuristic.
+// Column-slice width of the EXACT kernels (requires d % 4 == 0 and 16-byte aligned operands; n_slices =
+// ceil(d / slice), a partial last slice is masked in the kernel).
+//   * d a multiple of 16: the largest fast width that divides d, capped so that the gather working set of one slice
+//     (n_src_rows * slice * 4 B) is friendlier to the 256 MiB Infinity Cache when the whole operand is far beyond it;
+//   * other d (e.g. --hidden 100 -> d = 100, 200): one masked slice of the next power of two up to 256 columns, and
+//     slices of 128 beyond that (the last one masked).
+// `forced` > 0 (plan option) overrides the heuristic.
 int pick_slice_cols(int d, int64_t n_src_rows, int forced, double avg_segment_nnz) {
     static const int widths[] = {256, 128, 64, 32, 16};
-    if (forced > 0 && d % forced == 0) return forced;  // a forced width that does not divide d falls back to the heuristic
+    if (forced > 0) return forced;
+    if (d % 16 != 0) {
+        if (d > 256) return 128;
+        int w = 16;
+        while (w < d) w *= 2;
+        return w;
+    }
     int best = 0;
     for (int w : widths) {
         if (d % w != 0) continue;
@@ -196,18 +206,36 @@ int pick_slice_cols(int d, int64_t n_src_rows, int forced, double avg_segment_nn
     return best;
 }
 
+// Forward launches whose X has a row stride that is a multiple of 1 KiB gather faster from a slice-major scratch
+// copy (see repack_slice_major_kernel).  Worth it when the operand is far beyond the caches and every row of X is
+// gathered often enough to amortise the copy (2 * n_cols * d * 4 bytes against nnz * d * 4 gathered bytes).
+// Returns the slice width of the scratch layout, 0 = do not repack.
+int repack_slice_cols(const h2gcn_plan* plan, int64_t nnz_sel, int n_sel, int64_t ldx, int d) {
+    if (plan->variant == 4) return 0;                       // variant 4: never repack (A/B measurements)
+    if (d % 64 != 0 || d < 128) return 0;
+    if ((ldx * 4) % 1024 != 0) return 0;                    // only power-of-two-ish strides alias
+    if ((double)plan->n_cols * d * 4.0 < 512.0 * 1024 * 1024) return 0;
+    if ((double)nnz_sel < 32.0 * (double)plan->n_cols) return 0;
+    // the slice width the plain launch would use: same width => same summation tree => bit-identical results
+    const int w = pick_slice_cols(d, plan->n_cols, plan->slice_cols, (double)nnz_sel / ((double)plan->n_rows * n_sel));
+    return (w == 64 || w == 128) && d % w == 0 && w < d ? w : 0;
+}
+
 template <bool SUM>
 int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_slice, int64_t n_src_rows,
            double avg_segment_nnz, hipStream_t stream) {
     using namespace h2gcn;
     // index prefetch across segments: pays on short segments (+4 % at mean degree 4), costs ~0.4 % on long ones;
     // variant 2 forces it, variant 3 forbids it (bitwise-identical results either way)
+    if (variant == 4) variant = 0;
     const bool pipe = (variant == 2 || (variant == 0 && avg_segment_nnz < 16.0)) && p.rows_per_wave * p.n_sel <= 32;
     const bool scalar128 = vec_ok && variant == 1 && p.d == 128;  // variant 1 only exists for d = 128
-    const int slice = (vec_ok && !scalar128) ? pick_slice_cols(p.d, n_src_rows, forced_slice, avg_segment_nnz) : 0;
+    const bool sliced_ok = vec_ok && p.d % 4 == 0;                // float4 lanes; a partial last slice is masked
+    const int slice = (sliced_ok && !scalar128) ? pick_slice_cols(p.d, n_src_rows, forced_slice, avg_segment_nnz) : 0;
     const bool exact = slice > 0 || scalar128;
     p.slice_cols = exact ? (slice > 0 ? slice : 128) : p.d;
-    p.n_slices = exact ? p.d / p.slice_cols : 1;
+    p.n_slices = exact ? (p.d + p.slice_cols - 1) / p.slice_cols : 1;
+    if (p.src_slice_stride == 0) p.src_slice_stride = p.slice_cols;  // row-major source
     p.blocks_per_slice = (int64_t)p.n_long + p.tiles_per_xcd * kNumXcd;
     const int64_t n_blocks = p.blocks_per_slice * p.n_slices;
     if (n_blocks <= 0) return H2GCN_OK;
@@ -236,10 +264,8 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
         H2GCN_LAUNCH(4, 8, true);
     } else if (slice == 16) {
         H2GCN_LAUNCH(4, 4, true);  // 64-byte rows, 16 neighbours per load instruction (narrow exchange chunks)
-    } else if (vec_ok && p.d % 4 == 0) {
-        H2GCN_LAUNCH(4, 64, false);
     } else {
-        H2GCN_LAUNCH(1, 64, false);
+        H2GCN_LAUNCH(1, 64, false);  // d % 4 != 0 or unaligned operands: scalar column-tiled path
     }
 #undef H2GCN_LAUNCH
     H2GCN_HIP_TRY(hipGetLastError());
@@ -442,8 +468,27 @@ int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t*
     return H2GCN_OK;
 }
 
+size_t h2gcn_spmm_workspace_bytes(const h2gcn_plan_t* plan, uint32_t hop_mask, int64_t ldx, int32_t d) {
+    if (!plan || d < 1 || ldx < d) return 0;
+    uint32_t mask;
+    if (resolve_mask(plan, hop_mask, &mask) != H2GCN_OK) return 0;
+    int64_t nnz_sel = 0;
+    for (int k = 0; k < plan->n_hops; ++k)
+        if (mask & (1u << k)) nnz_sel += plan->fwd[k].nnz;
+    int n_sel = 0;
+    for (int k = 0; k < plan->n_hops; ++k) n_sel += (mask >> k) & 1u;
+    if (plan->n_rows == 0 || n_sel == 0) return 0;
+    return repack_slice_cols(plan, nnz_sel, n_sel, ldx, d) > 0 ? (size_t)plan->n_cols * (size_t)d * 4 : 0;
+}
+
 int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X, int64_t ldx, int32_t d,
                         float* Y, int64_t ldy_row, int64_t ldy_hop, void* stream_v) {
+    return h2gcn_spmm_hops_ws_f32(plan, hop_mask, X, ldx, d, Y, ldy_row, ldy_hop, nullptr, 0, stream_v);
+}
+
+int h2gcn_spmm_hops_ws_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X, int64_t ldx, int32_t d,
+                           float* Y, int64_t ldy_row, int64_t ldy_hop, void* workspace, size_t workspace_bytes,
+                           void* stream_v) {
     try {
         if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
         uint32_t mask;
@@ -487,8 +532,24 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
         p.n_tiles = (p.n_rows + rows_per_tile - 1) / rows_per_tile;
         p.tiles_per_xcd = (p.n_tiles + h2gcn::kNumXcd - 1) / h2gcn::kNumXcd;
         // 32-bit gather offsets when the farthest byte of X is below 4 GiB
-        const bool off32 = ((double)(plan->n_cols > 0 ? plan->n_cols - 1 : 0) * (double)ldx + d) * 4.0 < 4294967296.0;
-        return launch<false>(p, plan->variant, vec_ok, off32, plan->slice_cols, plan->n_cols,
+        bool off32 = ((double)(plan->n_cols > 0 ? plan->n_cols - 1 : 0) * (double)ldx + d) * 4.0 < 4294967296.0;
+        int forced_slice = plan->slice_cols;
+        const int rs = (workspace && vec_ok && aligned16(workspace)) ? repack_slice_cols(plan, nnz_sel, s, ldx, d) : 0;
+        if (rs > 0 && workspace_bytes >= (size_t)plan->n_cols * (size_t)d * 4) {
+            // slice-major scratch copy of X, then gather slice q from the contiguous block W[q] = [n_cols, rs]
+            const int n_slices = d / rs;
+            const int64_t total = plan->n_cols * (int64_t)(d / 4);
+            const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 64);
+            hipLaunchKernelGGL(h2gcn::repack_slice_major_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_v, X, ldx,
+                               plan->n_cols, n_slices, rs, (float*)workspace);
+            H2GCN_HIP_TRY(hipGetLastError());
+            p.src = (const float*)workspace;
+            p.ld_src = rs;
+            p.src_slice_stride = plan->n_cols * (int64_t)rs;
+            forced_slice = rs;
+            off32 = (double)plan->n_cols * (double)d * 4.0 < 4294967296.0;
+        }
+        return launch<false>(p, plan->variant, vec_ok, off32, forced_slice, plan->n_cols,
                              (double)nnz_sel / ((double)p.n_rows * s), (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_f32");

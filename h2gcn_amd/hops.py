@@ -63,6 +63,8 @@ class HopPlan:
         self.colidx = list(colidx)
         self.vals = list(vals)
         self._handle = C.c_void_p()
+        #: let launches use scratch memory for the slice-major copy of X (see h2gcn_spmm_workspace_bytes)
+        self.use_workspace = True
 
         L = _capi.lib()
         arr_t = C.c_void_p * H
@@ -157,11 +159,17 @@ class HopPlan:
         if self.n_rows == 0:
             return out
         L = _capi.lib()
+        mask = self._mask(hops)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            st = L.h2gcn_spmm_hops_f32(self._handle, self._mask(hops), C.c_void_p(x.data_ptr()), x.stride(0), d,
-                                       C.c_void_p(out.data_ptr()), out.stride(0), out.stride(1) if h_sel > 1 else d,
-                                       C.c_void_p(stream))
+            # scratch for the slice-major copy of X the library wants when X's row stride is a multiple of 1 KiB
+            # (0 bytes otherwise); a torch allocation, so it is stream-ordered and capturable in a hipGraph
+            ws_bytes = int(L.h2gcn_spmm_workspace_bytes(self._handle, mask, x.stride(0), d)) if self.use_workspace else 0
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device) if ws_bytes else None
+            st = L.h2gcn_spmm_hops_ws_f32(self._handle, mask, C.c_void_p(x.data_ptr()), x.stride(0), d,
+                                          C.c_void_p(out.data_ptr()), out.stride(0), out.stride(1) if h_sel > 1 else d,
+                                          C.c_void_p(ws.data_ptr() if ws is not None else None), ws_bytes,
+                                          C.c_void_p(stream))
         _capi.check(st)
         return out
 

@@ -90,6 +90,9 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
                   n_hops=(tensors["adj_hops"].n_hops if tensors["adj_hops"] is not None else 0),
                   sparse_input=not dense_features, l2_regularize_weight=l2_regularize_weight).to(device)
     sharded = _is_sharded()
+    if sharded:  # replicas must start identical whatever the seeding on each rank (e.g. --random_seed 0)
+        for p_ in model.parameters():
+            dist.broadcast(p_.data, src=0)
     use_graphs = not getattr(args, "_no_hipgraph", False) and optimizer.lower() == "adam" and not sharded
     optimizer = make_optimizer(optimizer, model.parameters(), lr, capturable=use_graphs)
     snapshot = logger.BestSnapshot()
@@ -145,6 +148,9 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
         args.objects["epoch_stats"] = stats
         if not _is_sharded() or dist.get_rank() == 0:
             stats_printer(epoch, stats)
+            if getattr(args, "json_stats", False):
+                import json
+                print(json.dumps({"epoch": epoch, **{k: v for k, v in stats.items() if isinstance(v, (int, float))}}))
         if args.objects["early_stopping"](stats["val_loss"]):
             print("Early stopping...")
             args.epochs = epoch
@@ -157,13 +163,17 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
     def post_train_callback(args):
         snapshot.restore(model, optimizer)
         stats = args.objects["test_step"](**args.objects["tensors"])
+        if args.objects["best_val_stats"] is None:  # --epochs 0: report the untrained model
+            raw = {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in stats.items()}
+            args.objects["best_val_stats"] = dict(raw, epoch=0, train_loss=float("nan"))
         args.objects["best_val_stats"]["monitor"] = stats["monitor"]
         if not _is_sharded() or dist.get_rank() == 0:
             print("Restoring the best performance model")
             print("Best performance:")
             stats_printer.from_dict(args.objects["best_val_stats"])
             _write_results(args)
-        snapshot.write(getattr(args, "checkpoint_dir", None))
+        if not _is_sharded() or dist.get_rank() == 0:
+            snapshot.write(getattr(args, "checkpoint_dir", None))
 
     args.objects.update(model=model, optimizer=optimizer, checkpoint=snapshot, train_step=train_step,
                         test_step=test_step, predict_step=predict_step, embed_step=embed_step)
@@ -266,6 +276,7 @@ class _GraphedSteps:
             eager_out = self.eager_train(**tensors)  # it is also this epoch's real update
             self.eager_test(**tensors)
         torch.cuda.current_stream(self.device).wait_stream(side)
+        self.pending_eager_out = eager_out  # if capture fails below, this epoch's update has already happened
         self.optimizer.zero_grad(set_to_none=True)
         g_train = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_train):
@@ -288,7 +299,10 @@ class _GraphedSteps:
                     print(f"hipGraph capture unavailable ({type(e).__name__}: {e}); continuing eagerly")
                     self.failed, self.train_graph, self.test_graph = True, None, None
                     torch.cuda.synchronize()
-                    return self.eager_train(**tensors)
+                    done = getattr(self, "pending_eager_out", None)
+                    self.pending_eager_out = None
+                    # the eager pass inside _capture already applied this epoch's update: do not step twice
+                    return done if done is not None else self.eager_train(**tensors)
             self.train_graph.replay()
             return dict(self.train_out)
 
@@ -319,6 +333,8 @@ class _SparseToDense(torch.nn.Module):
     """``I`` token: the sparse feature operand as a dense matrix (reference ``tf.sparse.to_dense``, ``:263-265``)."""
 
     def forward(self, plan):
+        if isinstance(plan, torch.Tensor):  # dense-ish features are handed over as a matrix already
+            return plan
         csr = torch.sparse_csr_tensor(plan.rowptr[0], plan.colidx[0].to(torch.int64), plan.vals[0],
                                       size=(plan.n_rows, plan.n_cols))
         return csr.to_dense()

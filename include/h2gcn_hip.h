@@ -67,7 +67,8 @@ typedef struct h2gcn_plan_opts {
     int32_t rows_per_wave;       /* consecutive rows a wave walks in the regular path; default 4           */
     int32_t variant;             /* kernel variant: 0 = default (index prefetch across segments when segments
                                     average < 16 nonzeros); 1 = scalar-addressed float2 gathers at d=128;
-                                    2 = always prefetch; 3 = never prefetch                                   */
+                                    2 = always prefetch; 3 = never prefetch; 4 = default, but never use the
+                                    slice-major scratch copy (A/B measurements)                               */
     int32_t slice_cols;          /* feature columns per slice of the slice-major schedule: 16/32/64/128/256,
                                     0 = heuristic (narrower slices when X is far beyond the Infinity Cache)  */
     int32_t reserved[2];
@@ -136,6 +137,20 @@ int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t*
  */
 int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X_dev, int64_t ldx,
                         int32_t d, float* Y_dev, int64_t ldy_row, int64_t ldy_hop, void* stream);
+
+/*
+ * Same launch with caller-provided scratch.  When the row stride of X is a multiple of 1 KiB (e.g. a contiguous
+ * [N, 256] embedding) and the operand is far beyond the caches, gathering column slices straight out of X wastes
+ * three quarters of the cache sets; the launch then first copies X into a slice-major layout inside `workspace`
+ * (one streaming pass, ~3 % of the launch) and gathers from there.  h2gcn_spmm_workspace_bytes() says how much
+ * scratch such a launch wants (0 = the plain launch is already the fastest); a NULL / too small workspace simply
+ * selects the plain launch.  Results are bit-identical either way.  The scratch is only used by this launch (on
+ * `stream`); launches that may run concurrently need separate scratch.
+ */
+size_t h2gcn_spmm_workspace_bytes(const h2gcn_plan_t* plan, uint32_t hop_mask, int64_t ldx, int32_t d);
+int h2gcn_spmm_hops_ws_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X_dev, int64_t ldx,
+                           int32_t d, float* Y_dev, int64_t ldy_row, int64_t ldy_hop, void* workspace_dev,
+                           size_t workspace_bytes, void* stream);
 
 /*
  * Adjoint (backward wrt X):

@@ -66,3 +66,15 @@ def load_syn_products_golden():
     n = len(z["indptr"]) - 1
     a = sp.csr_matrix((np.ones(len(z["indices"]), dtype=np.float32), z["indices"], z["indptr"]), shape=(n, n))
     return a, z["labels"], float(z["homophily"])
+
+
+def golden_weight(index, shape, kind="kernel"):
+    """Weight number `index` (creation order) of the glue fixtures (tests/golden/glue_cora.*): regenerable, so the
+    fixture stores shapes only.  Glorot-uniform kernels, small uniform biases, one PCG64 stream per weight."""
+    import numpy as np
+
+    rng = np.random.Generator(np.random.PCG64(977 + int(index)))
+    if kind == "bias":
+        return rng.uniform(-0.1, 0.1, shape).astype(np.float32)
+    lim = np.sqrt(6.0 / float(sum(shape)))
+    return rng.uniform(-lim, lim, shape).astype(np.float32)

@@ -22,6 +22,11 @@ Fixtures
 * dsl_parse.json         parse_network_setup() output for the network strings used by the reference configs.
 * cora_layer_outputs.npz r1 / r2 of H2GCN-2 on the golden Cora operands (row subset + fp64 column sums), via scipy.
 * syn_products.npz       one graph from the reference generator (n=10000, 10 classes, m=6, h=0.2) as CSR.
+* glue_cora.npz/.json    the reference's OWN `_layers.py` / `H2GCN.py` / `_metrics.py` executed under a numpy/scipy
+                         stand-in for TensorFlow (tests/golden/_tf_standin.py) on the golden Cora operands with
+                         regenerable weights (conftest.golden_weight): logits, every tagged activation (row subset +
+                         fp64 column sums), loss / accuracy / L2 term.  Pins the interpreter GLUE (stack axis, hop
+                         filter, concat order, slices, tag store, bias/activation order) -- not TF's kernels.
 """
 import argparse
 import json
@@ -185,6 +190,87 @@ def dsl_fixture():
     print("dsl strings:", len(res))
 
 
+GLUE_NETWORKS = [
+    "M64-R-T1-G-V-T2-G-V-C1-C2-D0.5-MO",            # H2GCN-2 (default, h2gcn/models/H2GCN.py:12)
+    "M64-R-T1-G-V-C1-D0.5-MO",                      # H2GCN-1
+    "M-R-T1-G0-V-T2-G0_1-V-C1_2-S1_0_32-D-MO",      # hop filters, multi-tag concat, slice of a tagged output
+    "I-T1-G-V-C1-M64-R-D0.5-MO",                    # identity (dense features) first, aggregation of raw features
+    "F64-R-E-D-FO",                                 # bias layers
+    "M64-T1-G1-V-T2-G-V-C2_1-MO",                   # single-hop filter, reversed tag list in the concat
+]
+
+
+def glue_fixture():
+    """Run the reference's model code (its own source, imported in place) under the TF stand-in."""
+    import importlib
+    import importlib.util
+
+    sys.path.insert(0, str(HERE))
+    sys.path.insert(0, str(HERE.parent))
+    import _tf_standin
+    from conftest import golden_weight, load_planetoid_golden
+
+    tf = _tf_standin.install()
+    for name in ("modules", "modules.logger", "modules.controller", "modules.monitor"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["modules"].logger = sys.modules["modules.logger"]
+    sys.modules["modules"].controller = sys.modules["modules.controller"]
+    sys.modules["modules"].monitor = sys.modules["modules.monitor"]
+    pkg_dir = REF / "h2gcn/models"
+    for k in [k for k in sys.modules if k.startswith("ref_glue")]:
+        del sys.modules[k]
+    spec = importlib.util.spec_from_file_location("ref_glue", pkg_dir / "__init__.py", submodule_search_locations=[str(pkg_dir)])
+    pkg = importlib.util.module_from_spec(spec)
+    sys.modules["ref_glue"] = pkg
+    spec.loader.exec_module(pkg)                              # imports the reference's real _layers.py
+    H = importlib.import_module("ref_glue.H2GCN")             # the reference's real H2GCN.py (+ _metrics.py)
+
+    g = load_planetoid_golden("cora")
+    n = g["n"]
+    feats = tf.SparseTensor(g["feat_rownorm"])
+    adjhops = [tf.SparseTensor(g["hop1_sym"]), tf.SparseTensor(g["hop2_sym"])]
+    labels = (g["y_all"] * g["train_mask"][:, None]).astype(np.float32)
+    deg2 = np.diff(g["hop2_sym"].indptr)
+    rows = np.array(sorted(set([0, 1, n - 1, int(np.diff(g["hop1_sym"].indptr).argmax()), int(deg2.argmax())]
+                               + np.where(deg2 == 0)[0][:6].tolist() + list(range(50, 2700, 97)))))
+    out, meta = {"rows": rows}, {"networks": GLUE_NETWORKS, "l2": 5e-4, "entries": []}
+    for i, net in enumerate(GLUE_NETWORKS):
+        _tf_standin.reset_weights(golden_weight)
+        setups = pkg.parse_network_setup(net, 7, _dense_units=64, _dropout_rate=0.5, parse_preprocessing=True)
+        model = H.H2GCN(setups, l2_regularize_weight=5e-4)
+        acts = {}
+        logits = model(None, feats, adjhops, training=False, saveActivations=None)
+        # tagged outputs: re-run the reference's loop bookkeeping through its own tagsDict
+        tagged = {}
+        x = feats
+        for ind, layer in enumerate(model.layer_objs):
+            if ind in model.concat_inds:
+                x = layer(x, **tagged)
+            elif ind in model.graph_hops_inds:
+                x = layer(adjhops, x)
+            else:
+                x = layer(x)
+            if ind in model.tagsDict:
+                tagged[model.tagsDict[ind]] = x
+        assert np.array_equal(x, logits)
+        loss = float(model._loss(logits, labels, g["train_mask"]))
+        acc = float(H.masked_accuracy(logits, labels, g["train_mask"]))
+        reg = float(tf.math.add_n(model.losses))
+        out[f"n{i}_logits"] = logits.astype(np.float32)
+        for tag, v in tagged.items():
+            v = np.asarray(v)
+            out[f"n{i}_tag{tag}_rows"] = v[rows].astype(np.float32)
+            out[f"n{i}_tag{tag}_colsum64"] = v.astype(np.float64).reshape(n, -1).sum(0)
+        meta["entries"].append({"network": net, "weights": [[k, list(sh)] for k, sh in _tf_standin._WEIGHT_LOG],
+                                "tags": {t: list(np.asarray(v).shape) for t, v in tagged.items()},
+                                "loss": loss, "train_acc": acc, "l2_term": reg})
+        print("glue:", net, "logits", logits.shape, "loss %.6f acc %.4f" % (loss, acc), "weights", _tf_standin._WEIGHT_LOG)
+    np.savez_compressed(HERE / "glue_cora.npz", **out)
+    (HERE / "glue_cora.json").write_text(json.dumps(meta, indent=1))
+    for name in ("tensorflow", "tensorflow.keras", "tensorflow.sparse"):
+        sys.modules.pop(name, None)
+
+
 def syn_fixture():
     import importlib.util
 
@@ -212,6 +298,7 @@ def main():
     planetoid_fixture(ref, "ind.citeseer")
     dsl_fixture()
     layer_output_fixture()
+    glue_fixture()
     if a.syn:
         make_syn(syn_fixture())
 

@@ -65,6 +65,52 @@ def test_forward_matches_oracle_interpreter(tmp_path, network):
     assert abs(l_gpu - l_cpu) <= 1e-5
 
 
+def _glue_entries():
+    import json
+
+    from conftest import GOLDEN
+    return json.loads((GOLDEN / "glue_cora.json").read_text())["entries"]
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_forward_matches_reference_glue_fixture(tmp_path, idx):
+    """HIP path vs tests/golden/glue_cora.*: logits / tagged activations / loss produced by the REFERENCE'S OWN
+    `_layers.py` + `H2GCN.py` + `_metrics.py` (run under a numpy stand-in for TF by tests/golden/make_golden.py) on
+    the golden Cora operands with the regenerable golden weights.  Both the concat-free fused propagation and the
+    layer-by-layer interpreter are checked."""
+    from conftest import GOLDEN, golden_weight
+
+    entry = _glue_entries()[idx]
+    z = np.load(GOLDEN / "glue_cora.npz")
+    g, data, tensors, setup, model = _setup(tmp_path, entry["network"])
+    model.eval()
+    params = []
+    for layer in model.regularized:
+        params.append(layer.kernel)
+        if layer.bias is not None:
+            params.append(layer.bias)
+    assert [list(p.shape) for p in params] == [shape for _, shape in entry["weights"]]
+    with torch.no_grad():
+        for i, ((kind, shape), p) in enumerate(zip(entry["weights"], params)):
+            p.copy_(torch.from_numpy(golden_weight(i, tuple(shape), kind)))
+    want = z[f"n{idx}_logits"]
+    for fuse in (True, False):
+        tagged = {}
+        with torch.no_grad():
+            logits = model(tensors["adj"], tensors["features"], tensors["adj_hops"], tagged_out=tagged, fuse=fuse)
+        assert np.abs(logits.cpu().numpy() - want).max() <= 1e-5, fuse
+        assert set(tagged) == set(entry["tags"])
+        for tag, shape in entry["tags"].items():
+            v = tagged[tag].cpu().numpy()
+            assert list(v.shape) == shape, tag
+            assert np.abs(v[z["rows"]] - z[f"n{idx}_tag{tag}_rows"]).max() <= 1e-5, tag
+            assert np.allclose(v.astype(np.float64).reshape(g["n"], -1).sum(0), z[f"n{idx}_tag{tag}_colsum64"], rtol=0, atol=1e-3)
+    loss = model.loss(logits, tensors["y_train"], tensors["train_mask"]).item()
+    assert abs(loss - entry["loss"]) <= 1e-5
+    from h2gcn_amd.models._metrics import masked_accuracy
+    assert abs(masked_accuracy(logits, tensors["y_train"], tensors["train_mask"]).item() - entry["train_acc"]) <= 1e-6
+
+
 def test_syn_products_h2gcn2_logits(tmp_path):
     """BASELINE.json configs[1]: syn-products-shaped graph (reference generator, n=10k, h=0.2), synthetic
     class-conditional features d=100, `--no_feature_normalize` (experiments/h2gcn/configs/syn-products/h2gcn.json),

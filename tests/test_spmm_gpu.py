@@ -131,6 +131,69 @@ def test_feature_widths(d):
     assert_close(y, hops, x)
 
 
+@pytest.mark.parametrize("d", [20, 36, 100, 132, 200, 300, 452])
+def test_partial_last_slice_widths(d):
+    """Widths that are multiples of 4 but not of the slice width (--hidden 100 -> d = 100, 200) run through the
+    sliced float4 kernels with a masked last slice: every slice width, the pipelined segment walk, a long row, and the
+    adjoint, all against the oracle; the neighbouring memory of a strided output must stay untouched."""
+    from h2gcn_amd import HopPlan
+
+    n = 700
+    hops = [rand_csr(n, n, 0.01, 1, empty_frac=0.1), rand_csr(n, n, 0.06, 2, empty_frac=0.2)]
+    hops[0] = sp.csr_matrix(sp.vstack([hops[0][:5], sp.csr_matrix(np.full((1, n), 0.01, dtype=np.float32)), hops[0][6:]]))
+    rng = np.random.default_rng(d)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    w = rng.uniform(-1, 1, (n, 2, d)).astype(np.float32)
+    want = og.gcn_layer_f64acc(hops, x)
+    want_t = og.gcn_layer_grad_c(hops, w, n)
+    for sc in (0, 16, 64, 128, 256):
+        for variant in (0, 2):
+            plan = HopPlan.from_scipy(hops, dev(), slice_cols=sc, variant=variant, long_row_threshold=128, build_transpose=True)
+            ybuf = torch.full((n, 2, d + 12), 7.0, device=dev())          # guard columns right of every hop block
+            y = plan.spmm(torch.from_numpy(x).to(dev()), out=ybuf[:, :, :d])
+            assert_close(y.cpu().numpy(), hops, x, want)
+            assert bool((ybuf[:, :, d:] == 7.0).all()), (sc, variant)
+            dx = plan.spmm_t(torch.from_numpy(w).to(dev()))
+            assert np.abs(dx.cpu().numpy() - want_t).max() <= 2e-5, (sc, variant)
+
+
+def test_slice_major_scratch_copy_is_bitwise_identical():
+    """X with a 1 KiB row stride (contiguous [N, 256]) far beyond the caches: the launch gathers from a slice-major
+    scratch copy (h2gcn_spmm_hops_ws_f32); same bits as the plain launch, sampled rows against the oracle."""
+    import ctypes as C
+
+    from h2gcn_amd import HopPlan, _capi, synth
+
+    n, d, device = 540_000, 256, dev()
+    degs = [synth.synth_degrees(n, 9_500_000, s, n) for s in (5, 6)]
+    csr = [synth.synth_hop_rows(degs[k], n, (5, 6)[k], 0, n, device) for k in range(2)]
+    # (64-column slices forced: at this size -- X = 553 MB -- the heuristic would not slice, at products scale it does)
+    plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n, slice_cols=64)
+    x = synth.synth_features(d, 7, 0, n, device)
+    L = _capi.lib()
+    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, d, d) == n * d * 4          # contiguous: 1 KiB stride
+    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, d + 32, d) == 0             # padded rows do not alias
+    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 64, 64) == 0
+    y_ws = plan.spmm(x)
+    plan.use_workspace = False
+    y_plain = plan.spmm(x)
+    assert torch.equal(y_ws, y_plain)
+    # a workspace that is too small silently selects the plain launch
+    small = torch.empty(1024, dtype=torch.uint8, device=device)
+    y3 = torch.empty_like(y_ws)
+    _capi.check(L.h2gcn_spmm_hops_ws_f32(plan._handle, 0, C.c_void_p(x.data_ptr()), d, d, C.c_void_p(y3.data_ptr()), 2 * d, d,
+                                         C.c_void_p(small.data_ptr()), 1024, None))
+    torch.cuda.synchronize()
+    assert torch.equal(y3, y_plain)
+    for r0 in (0, 12345, n - 8):
+        parts = [synth.synth_hop_rows_np(degs[k], n, (5, 6)[k], r0, r0 + 8) for k in range(2)]
+        cols = np.unique(np.concatenate([q[1] for q in parts]))
+        xs = x[torch.from_numpy(cols.astype(np.int64)).to(device)].cpu().numpy()
+        remap = {c: i for i, c in enumerate(cols)}
+        local = [(q[0], np.array([remap[c] for c in q[1]], dtype=np.int32), q[2]) for q in parts]
+        assert np.abs(y_ws[r0:r0 + 8].cpu().numpy() - og.rows_subset(local, xs, list(range(8)))).max() <= ATOL
+
+
 @pytest.mark.parametrize("n_rows,n_cols", [(1, 1), (5, 9), (63, 64), (64, 63), (65, 1000), (1000, 17), (4097, 333)])
 def test_ragged_shapes_rectangular(n_rows, n_cols):
     hops = [rand_csr(n_rows, n_cols, 0.3, 3), rand_csr(n_rows, n_cols, 0.6, 4, empty_frac=0.2)]
