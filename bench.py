@@ -342,6 +342,7 @@ def main():
             "parallelism": f"row-partition x{world}" + (f", exchange of X per step: {exchange}" if world > 1 else ""),
             "kernel_variant": a.variant, "feature_chunks": chunk_label, "dist_backend": backend,
             "diagnostics": diagnostics, "slice_cols": a.slice_cols or "auto", "y_checksum": y_checksum,
+            "schedule": plan.schedule(layer.widths[0]),
             "t_fused_median_ms": kern_ms_median,
             "edges_per_s_from_median_kernel_time": sum(nnz_local) / (kern_ms_median * 1e-3),
         },
@@ -385,10 +386,10 @@ def main():
         del dy
     if rank == 0 and world == 1 and not a.no_probe:
         # live ceilings of this box at the kernel's gather working set (one column slice of X)
-        slice_cols = a.slice_cols or (64 if (d % 64 == 0 and n * 128 * 4 > 768 * 2**20 and d >= 128) else min(d, 256))
+        slice_cols = min(plan.schedule(d)["slice_cols"], d)
         pr = probe_ceilings(n * slice_cols * 4 / 2**20, slice_cols * 4)
         out["roofline"]["gather_ceiling_GBps"] = pr.get("gather_GBps")
-        out["roofline"]["peak_achievable"] = pr.get("copy_GBps")
+        out["roofline"]["peak_achievable"] = max(pr.get("copy_GBps") or 0.0, pr.get("stream_read_GBps") or 0.0) or None
         out["roofline"]["ceilings"] = pr
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:

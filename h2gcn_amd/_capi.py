@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = (
     "h2gcn_plan_info",
     "h2gcn_spmm_hops_f32",
     "h2gcn_spmm_hops_T_f32",
+    "h2gcn_plan_schedule",
     "h2gcn_spmm_workspace_bytes",
     "h2gcn_spmm_hops_ws_f32",
     "h2gcn_xchg_create",
@@ -122,6 +123,8 @@ def lib() -> C.CDLL:
     L.h2gcn_spmm_hops_T_f32.argtypes = [
         C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
     ]
+    L.h2gcn_plan_schedule.restype = C.c_int
+    L.h2gcn_plan_schedule.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int64, C.c_int32] + [C.POINTER(C.c_int32)] * 4
     L.h2gcn_spmm_workspace_bytes.restype = C.c_size_t
     L.h2gcn_spmm_workspace_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_int32]
     L.h2gcn_spmm_hops_ws_f32.restype = C.c_int

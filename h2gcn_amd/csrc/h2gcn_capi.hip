@@ -221,18 +221,34 @@ int repack_slice_cols(const h2gcn_plan* plan, int64_t nnz_sel, int n_sel, int64_
     return (w == 64 || w == 128) && d % w == 0 && w < d ? w : 0;
 }
 
+struct Schedule {
+    bool pipe, scalar128, exact;
+    int slice;
+};
+
+// The launch-time decisions (also reported by h2gcn_plan_schedule).
+Schedule decide(int variant, bool vec_ok, int d, int rows_per_wave, int n_sel, int forced_slice, int64_t n_src_rows,
+                double avg_segment_nnz) {
+    Schedule sc;
+    // index prefetch across segments: pays on short segments (+4 % at mean degree 4), costs ~0.4 % on long ones;
+    // variant 2 forces it, variant 3 forbids it (bitwise-identical results either way)
+    if (variant == 4) variant = 0;
+    sc.pipe = (variant == 2 || (variant == 0 && avg_segment_nnz < 16.0)) && rows_per_wave * n_sel <= 32;
+    sc.scalar128 = vec_ok && variant == 1 && d == 128;  // variant 1 only exists for d = 128
+    const bool sliced_ok = vec_ok && d % 4 == 0;        // float4 lanes; a partial last slice is masked
+    sc.slice = (sliced_ok && !sc.scalar128) ? pick_slice_cols(d, n_src_rows, forced_slice, avg_segment_nnz) : 0;
+    sc.exact = sc.slice > 0 || sc.scalar128;
+    sc.pipe = sc.pipe && sc.exact;
+    return sc;
+}
+
 template <bool SUM>
 int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_slice, int64_t n_src_rows,
            double avg_segment_nnz, hipStream_t stream) {
     using namespace h2gcn;
-    // index prefetch across segments: pays on short segments (+4 % at mean degree 4), costs ~0.4 % on long ones;
-    // variant 2 forces it, variant 3 forbids it (bitwise-identical results either way)
-    if (variant == 4) variant = 0;
-    const bool pipe = (variant == 2 || (variant == 0 && avg_segment_nnz < 16.0)) && p.rows_per_wave * p.n_sel <= 32;
-    const bool scalar128 = vec_ok && variant == 1 && p.d == 128;  // variant 1 only exists for d = 128
-    const bool sliced_ok = vec_ok && p.d % 4 == 0;                // float4 lanes; a partial last slice is masked
-    const int slice = (sliced_ok && !scalar128) ? pick_slice_cols(p.d, n_src_rows, forced_slice, avg_segment_nnz) : 0;
-    const bool exact = slice > 0 || scalar128;
+    const Schedule sc = decide(variant, vec_ok, p.d, p.rows_per_wave, p.n_sel, forced_slice, n_src_rows, avg_segment_nnz);
+    const bool pipe = sc.pipe, scalar128 = sc.scalar128, exact = sc.exact;
+    const int slice = sc.slice;
     p.slice_cols = exact ? (slice > 0 ? slice : 128) : p.d;
     p.n_slices = exact ? (p.d + p.slice_cols - 1) / p.slice_cols : 1;
     if (p.src_slice_stride == 0) p.src_slice_stride = p.slice_cols;  // row-major source
@@ -465,6 +481,32 @@ int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t*
     if (nnz) *nnz = plan->fwd[hop].nnz;
     if (n_long_segments) *n_long_segments = (int64_t)plan->fwd[hop].long_rows.size();
     if (has_transpose) *has_transpose = plan->has_transpose ? 1 : 0;
+    return H2GCN_OK;
+}
+
+int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, int64_t ld_src, int32_t d,
+                        int32_t* slice_cols, int32_t* n_slices, int32_t* index_prefetch, int32_t* scratch_copy) {
+    if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
+    uint32_t mask;
+    int st = resolve_mask(plan, hop_mask, &mask);
+    if (st != H2GCN_OK) return st;
+    if (d < 1 || ld_src < d) return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad width %d / stride %lld", d, (long long)ld_src);
+    if (adjoint && !plan->has_transpose) return fail(H2GCN_ERR_NO_TRANSPOSE, "plan was created without H2GCN_PLAN_BUILD_TRANSPOSE");
+    const std::vector<HopOperand>& ops = adjoint ? plan->adj : plan->fwd;
+    int64_t nnz_sel = 0;
+    int n_sel = 0;
+    for (int k = 0; k < plan->n_hops; ++k)
+        if (mask & (1u << k)) { nnz_sel += ops[k].nnz; ++n_sel; }
+    const int64_t n_out = adjoint ? plan->n_cols : plan->n_rows, n_src = adjoint ? plan->n_rows : plan->n_cols;
+    const double avg = n_out > 0 ? (double)nnz_sel / ((double)n_out * n_sel) : 0.0;
+    const bool vec_ok = ld_src % 4 == 0;  // 16-byte aligned base pointers assumed
+    const int rs = (!adjoint && vec_ok && n_out > 0) ? repack_slice_cols(plan, nnz_sel, n_sel, ld_src, d) : 0;
+    const Schedule sc = decide(plan->variant, vec_ok, d, plan->rows_per_wave, n_sel, rs > 0 ? rs : plan->slice_cols, n_src, avg);
+    const int w = sc.exact ? (sc.slice > 0 ? sc.slice : 128) : d;
+    if (slice_cols) *slice_cols = w;
+    if (n_slices) *n_slices = sc.exact ? (d + w - 1) / w : 1;
+    if (index_prefetch) *index_prefetch = sc.pipe ? 1 : 0;
+    if (scratch_copy) *scratch_copy = rs > 0 ? 1 : 0;
     return H2GCN_OK;
 }
 

@@ -1,0 +1,354 @@
+// rings.hip -- exact-k-hop neighbourhood rings on the device: the operand construction that FEEDS the hop
+// aggregation (reference `TransformSPAdj.nhoodSplit`, h2gcn/datasets/_dataset.py:138-158, and `.normalize`,
+// :109-124).
+//
+// The reference grows reachability with a host SpGEMM, `mt <- bin(mt @ (A + I))`, and takes `mt_k - mt_{k-1}`.  Here
+// a ring is computed row by row as a SET expression over CSR patterns (no values are multiplied -- the operation is
+// boolean):
+//
+//     out[i] = ( U_{j in F[i]} A[j]  U  U_p ADD_p[i]  U  ({i} if add_diag) )  \  ( U_q SUB_q[i]  U  ({i} if sub_diag) )
+//
+//   ring_k  = expand frontier F = ring_{k-1} through A, subtract ring_0 .. ring_{k-1} (ring_0 = I: sub_diag)
+//   a merged --adj_nhood group such as "0,1" = no expansion, ADD = the member rings.
+//
+// One workgroup owns one output row at a time (rows are handed out by an atomic ticket, longest-first is not needed:
+// the work per row is bounded by its candidate count).  The row's candidate set lives in a TWO-LEVEL BITMAP:
+//   level 0: one bit per column (n bits) -- in LDS when n <= kLdsBitmapCols, else in a per-workgroup slab of global
+//            scratch that stays L2-resident;
+//   level 1: one bit per level-0 word, always in LDS.
+// Marking is an LDS/L2 atomic OR per candidate (the expansion reads A's rows coalesced, one wave per frontier node);
+// subtraction clears bits; emission walks level 1, pops the set level-0 words in ascending column order (block-wide
+// prefix sum of the per-thread popcounts) and clears them on the way, so the bitmap is zero again for the next row.
+// Output columns therefore come out sorted -- the canonical order `tf.sparse.reorder` establishes
+// (_dataset.py:535) -- and every output element is written exactly once (two passes: count -> scan -> fill).
+// The kernels are integer/bit work bound by LDS atomics and the streaming reads of A: no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include "capi_internal.h"
+#include "h2gcn_hip.h"
+
+namespace {
+
+using h2gcn::fail;
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int64_t kLdsBitmapCols = 1 << 20;  // level 0 in LDS up to this many columns (128 KiB of the CU's 160 KiB)
+constexpr int kMaxPatterns = 8;
+
+struct Pattern {
+    const int64_t* rowptr;
+    const int32_t* colidx;
+};
+
+struct RingParams {
+    int64_t n;            // rows == columns
+    Pattern a;            // expansion operand A (self loops already removed); unused when frontier.rowptr == NULL
+    Pattern frontier;     // F: rows whose A-rows are united (NULL rowptr = no expansion)
+    Pattern add[kMaxPatterns];
+    Pattern sub[kMaxPatterns];
+    int n_add, n_sub;
+    int add_diag, sub_diag;
+    int64_t* counts;          // pass 1: counts[i] = |out[i]|
+    const int64_t* out_rowptr;  // pass 2
+    int32_t* out_colidx;        // pass 2
+    unsigned int* ticket;     // row dispenser
+    uint32_t* l0_scratch;     // level-0 slabs in global memory (gridDim.x * l0_words), zero-initialised; NULL = LDS
+    int64_t l0_words;         // ceil(n / 32)
+    int64_t l1_words;         // ceil(l0_words / 32)
+};
+
+template <bool L0_LDS>
+__device__ __forceinline__ void mark(uint32_t* l0, uint32_t* l1, int32_t c) {
+    const uint32_t w = (uint32_t)c >> 5, bit = 1u << (c & 31);
+    if constexpr (L0_LDS) {
+        atomicOr(&l0[w], bit);
+    } else {
+        __hip_atomic_fetch_or(&l0[w], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    atomicOr(&l1[w >> 5], 1u << (w & 31));
+}
+
+template <bool L0_LDS>
+__device__ __forceinline__ void unmark(uint32_t* l0, int32_t c) {
+    const uint32_t w = (uint32_t)c >> 5, bit = 1u << (c & 31);
+    if constexpr (L0_LDS) {
+        atomicAnd(&l0[w], ~bit);
+    } else {
+        __hip_atomic_fetch_and(&l0[w], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// FILL == false: counts[i]; FILL == true: out_colidx[out_rowptr[i] ...] in ascending order.
+template <bool L0_LDS, bool FILL>
+__global__ __launch_bounds__(kThreads) void ring_kernel(const RingParams p) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* l1 = lds;                                   // [l1_words]
+    uint32_t* l0 = L0_LDS ? lds + p.l1_words : p.l0_scratch + (int64_t)blockIdx.x * p.l0_words;
+    __shared__ unsigned int row_s;
+    __shared__ uint32_t scan_s[kThreads];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // the bitmaps start zeroed (LDS part here, the global slabs by the host) and are left zeroed by every row
+    for (int64_t w = tid; w < p.l1_words + (L0_LDS ? p.l0_words : 0); w += kThreads) lds[w] = 0;
+    __syncthreads();
+
+    while (true) {
+        if (tid == 0) row_s = atomicAdd(p.ticket, 1u);
+        __syncthreads();
+        const int64_t i = row_s;
+        if (i >= p.n) break;
+
+        // ---- mark: expansion of the frontier through A, one wave per frontier node, lanes over its neighbours
+        if (p.frontier.rowptr) {
+            const int64_t fb = p.frontier.rowptr[i], fe = p.frontier.rowptr[i + 1];
+            for (int64_t f = fb + wave; f < fe; f += kWaves) {
+                const int64_t j = p.frontier.colidx[f];
+                const int64_t ab = p.a.rowptr[j], ae = p.a.rowptr[j + 1];
+                for (int64_t e = ab + lane; e < ae; e += 64) mark<L0_LDS>(l0, l1, __builtin_nontemporal_load(p.a.colidx + e));
+            }
+        }
+        for (int q = 0; q < p.n_add; ++q) {
+            const int64_t b = p.add[q].rowptr[i], e = p.add[q].rowptr[i + 1];
+            for (int64_t t = b + tid; t < e; t += kThreads) mark<L0_LDS>(l0, l1, p.add[q].colidx[t]);
+        }
+        if (p.add_diag && tid == 0) mark<L0_LDS>(l0, l1, (int32_t)i);
+        __syncthreads();
+        // ---- subtract
+        for (int q = 0; q < p.n_sub; ++q) {
+            const int64_t b = p.sub[q].rowptr[i], e = p.sub[q].rowptr[i + 1];
+            for (int64_t t = b + tid; t < e; t += kThreads) unmark<L0_LDS>(l0, p.sub[q].colidx[t]);
+        }
+        if (p.sub_diag && tid == 0) unmark<L0_LDS>(l0, (int32_t)i);
+        __syncthreads();
+
+        // ---- emit: thread t owns the contiguous level-1 word range [t*per, (t+1)*per) = a contiguous column range
+        const int64_t per = (p.l1_words + kThreads - 1) / kThreads;
+        const int64_t w1b = min((int64_t)tid * per, p.l1_words), w1e = min(w1b + per, p.l1_words);
+        uint32_t mine = 0;
+        for (int64_t w1 = w1b; w1 < w1e; ++w1) {
+            uint32_t m = l1[w1];
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1;
+                mine += __builtin_popcount(l0[w1 * 32 + b]);
+            }
+        }
+        // block-wide exclusive prefix sum of `mine` (ascending thread id = ascending column)
+        scan_s[tid] = mine;
+        __syncthreads();
+        for (int off = 1; off < kThreads; off <<= 1) {
+            const uint32_t v = tid >= off ? scan_s[tid - off] : 0;
+            __syncthreads();
+            scan_s[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t before = scan_s[tid] - mine;
+        if (!FILL && tid == kThreads - 1) p.counts[i] = scan_s[tid];
+        int64_t pos = FILL ? p.out_rowptr[i] + before : 0;
+        for (int64_t w1 = w1b; w1 < w1e; ++w1) {
+            uint32_t m = l1[w1];
+            if (!m) continue;
+            l1[w1] = 0;
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1;
+                const int64_t w0 = w1 * 32 + b;
+                uint32_t bits = l0[w0];
+                l0[w0] = 0;
+                if constexpr (FILL) {
+                    while (bits) {
+                        const int c = __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        p.out_colidx[pos++] = (int32_t)(w0 * 32 + c);
+                    }
+                }
+            }
+        }
+        __syncthreads();  // bitmaps are zero again; row_s may be overwritten
+    }
+}
+
+// vals[e] of a square hop matrix given as a CSR PATTERN (all stored entries are 1, as nhoodSplit produces):
+//   mode 1 (SYM): fp32( (s[deg_i] * 1.0) * s[deg_j] ),  s = deg^-1/2 with inf -> 0   (_dataset.py:114-118)
+//   mode 2 (RW):  fp32( s[deg_i] * 1.0 ),               s = deg^-1   with inf -> 0   (_dataset.py:119-123)
+//   mode 0 (ORDINARY): 1
+// deg = row sums of THIS matrix = its row lengths.  `s_table[k]` holds the fp64 scaling of a row with k entries,
+// computed on the host with the reference's own numpy call (np.power) so that the fp64 products -- and the fp32
+// cast sparse2Tensor applies (:528-535) -- are bit-identical; the table depends on nothing but k.
+__global__ void normalize_pattern_kernel(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                         int mode, const double* __restrict__ s_table, float* __restrict__ vals) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += n_waves) {
+        const int64_t b = rowptr[i], e = rowptr[i + 1];
+        const double si = mode == 0 ? 1.0 : s_table[e - b];
+        for (int64_t t = b + lane; t < e; t += 64) {
+            double v = si * 1.0;
+            if (mode == 1) {
+                const int64_t j = colidx[t];
+                v = v * s_table[rowptr[j + 1] - rowptr[j]];
+            }
+            vals[t] = (float)v;
+        }
+    }
+}
+
+int check_pattern(const char* what, const int64_t* rp, const int32_t* ci) {
+    if (!rp) return fail(H2GCN_ERR_INVALID_ARGUMENT, "%s: rowptr is NULL", what);
+    (void)ci;
+    return H2GCN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t h2gcn_ring_scratch_bytes(int64_t n) {
+    if (n <= 0) return 64;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t l0_words = (n + 31) / 32;
+    const size_t slabs = n > kLdsBitmapCols ? (size_t)cus * 2 * (size_t)l0_words * 4 : 0;
+    return 64 + slabs;
+}
+
+static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_t* a_colidx, const int64_t* f_rowptr,
+                     const int32_t* f_colidx, int n_add, const int64_t* const* add_rowptr, const int32_t* const* add_colidx,
+                     int add_diag, int n_sub, const int64_t* const* sub_rowptr, const int32_t* const* sub_colidx, int sub_diag,
+                     int64_t* out_rowptr, int32_t* out_colidx, int64_t* nnz_out, void* scratch, size_t scratch_bytes,
+                     hipStream_t stream) {
+    if (n < 0 || n > 0x7fffffffLL) return fail(H2GCN_ERR_INVALID_ARGUMENT, "n = %lld (column ids are int32)", (long long)n);
+    if (n_add < 0 || n_add > kMaxPatterns || n_sub < 0 || n_sub > kMaxPatterns)
+        return fail(H2GCN_ERR_INVALID_ARGUMENT, "at most %d add / sub patterns", kMaxPatterns);
+    if (!out_rowptr) return fail(H2GCN_ERR_INVALID_ARGUMENT, "out_rowptr is NULL");
+    if (f_rowptr && (!a_rowptr)) return fail(H2GCN_ERR_INVALID_ARGUMENT, "a frontier needs the expansion operand A");
+    if (scratch_bytes < h2gcn_ring_scratch_bytes(n) || !scratch)
+        return fail(H2GCN_ERR_INVALID_ARGUMENT, "scratch of %zu bytes, need %zu (h2gcn_ring_scratch_bytes)", scratch_bytes,
+                    h2gcn_ring_scratch_bytes(n));
+    if (fill && !out_colidx) return fail(H2GCN_ERR_INVALID_ARGUMENT, "out_colidx is NULL");
+    RingParams p;
+    memset(&p, 0, sizeof(p));
+    p.n = n;
+    p.a = Pattern{a_rowptr, a_colidx};
+    p.frontier = Pattern{f_rowptr, f_colidx};
+    for (int q = 0; q < n_add; ++q) {
+        int st = check_pattern("add", add_rowptr[q], add_colidx[q]);
+        if (st != H2GCN_OK) return st;
+        p.add[q] = Pattern{add_rowptr[q], add_colidx[q]};
+    }
+    for (int q = 0; q < n_sub; ++q) {
+        int st = check_pattern("sub", sub_rowptr[q], sub_colidx[q]);
+        if (st != H2GCN_OK) return st;
+        p.sub[q] = Pattern{sub_rowptr[q], sub_colidx[q]};
+    }
+    p.n_add = n_add;
+    p.n_sub = n_sub;
+    p.add_diag = add_diag;
+    p.sub_diag = sub_diag;
+    p.l0_words = (n + 31) / 32;
+    p.l1_words = (p.l0_words + 31) / 32;
+    p.ticket = (unsigned int*)scratch;
+    if (n == 0) {
+        H2GCN_HIP_TRY(hipMemsetAsync(out_rowptr, 0, sizeof(int64_t), stream));
+        if (nnz_out) *nnz_out = 0;
+        return H2GCN_OK;
+    }
+    int dev = 0, cus = 256;
+    H2GCN_HIP_TRY(hipGetDevice(&dev));
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool l0_lds = n <= kLdsBitmapCols;
+    const size_t lds_bytes = (size_t)(p.l1_words + (l0_lds ? p.l0_words : 0)) * 4;
+    // workgroups per CU the LDS footprint allows (160 KiB per CU, keep some for the static arrays), at most 8
+    int per_cu = l0_lds ? (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (lds_bytes + 2048))) : 2;
+    unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)cus * per_cu);
+    if (!l0_lds) {
+        grid = (unsigned)std::min<int64_t>(n, (int64_t)cus * 2);
+        p.l0_scratch = (uint32_t*)((char*)scratch + 64);
+        H2GCN_HIP_TRY(hipMemsetAsync(p.l0_scratch, 0, (size_t)grid * p.l0_words * 4, stream));
+    }
+    H2GCN_HIP_TRY(hipMemsetAsync(p.ticket, 0, 64, stream));
+    if (!fill) {
+        p.counts = out_rowptr + 1;  // counts land in out_rowptr[1..n], the scan below turns them into row pointers
+        H2GCN_HIP_TRY(hipMemsetAsync(out_rowptr, 0, sizeof(int64_t), stream));
+        if (l0_lds) {
+            H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)ring_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL((ring_kernel<true, false>), dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+        } else {
+            hipLaunchKernelGGL((ring_kernel<false, false>), dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+        }
+        H2GCN_HIP_TRY(hipGetLastError());
+        // inclusive scan in place: out_rowptr[1..n]
+        size_t tmp_bytes = 0;
+        H2GCN_HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, p.counts, p.counts, (size_t)n, rocprim::plus<int64_t>(), stream));
+        void* tmp = nullptr;
+        H2GCN_HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+        hipError_t e = rocprim::inclusive_scan(tmp, tmp_bytes, p.counts, p.counts, (size_t)n, rocprim::plus<int64_t>(), stream);
+        int64_t total = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, out_rowptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return fail(H2GCN_ERR_HIP, "row-pointer scan failed: %s", hipGetErrorString(e));
+        if (nnz_out) *nnz_out = total;
+    } else {
+        p.out_rowptr = out_rowptr;
+        p.out_colidx = out_colidx;
+        if (l0_lds) {
+            H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)ring_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL((ring_kernel<true, true>), dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+        } else {
+            hipLaunchKernelGGL((ring_kernel<false, true>), dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+        }
+        H2GCN_HIP_TRY(hipGetLastError());
+    }
+    return H2GCN_OK;
+}
+
+int h2gcn_ring_count(int64_t n, const int64_t* a_rowptr, const int32_t* a_colidx, const int64_t* f_rowptr,
+                     const int32_t* f_colidx, int n_add, const int64_t* const* add_rowptr,
+                     const int32_t* const* add_colidx, int add_diag, int n_sub, const int64_t* const* sub_rowptr,
+                     const int32_t* const* sub_colidx, int sub_diag, int64_t* out_rowptr, int64_t* nnz_out,
+                     void* scratch, size_t scratch_bytes, void* stream) {
+    try {
+        return ring_pass(false, n, a_rowptr, a_colidx, f_rowptr, f_colidx, n_add, add_rowptr, add_colidx, add_diag, n_sub,
+                         sub_rowptr, sub_colidx, sub_diag, out_rowptr, nullptr, nnz_out, scratch, scratch_bytes, (hipStream_t)stream);
+    } catch (...) {
+        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in ring_count");
+    }
+}
+
+int h2gcn_ring_fill(int64_t n, const int64_t* a_rowptr, const int32_t* a_colidx, const int64_t* f_rowptr,
+                    const int32_t* f_colidx, int n_add, const int64_t* const* add_rowptr,
+                    const int32_t* const* add_colidx, int add_diag, int n_sub, const int64_t* const* sub_rowptr,
+                    const int32_t* const* sub_colidx, int sub_diag, const int64_t* out_rowptr, int32_t* out_colidx,
+                    void* scratch, size_t scratch_bytes, void* stream) {
+    try {
+        return ring_pass(true, n, a_rowptr, a_colidx, f_rowptr, f_colidx, n_add, add_rowptr, add_colidx, add_diag, n_sub,
+                         sub_rowptr, sub_colidx, sub_diag, const_cast<int64_t*>(out_rowptr), out_colidx, nullptr, scratch,
+                         scratch_bytes, (hipStream_t)stream);
+    } catch (...) {
+        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in ring_fill");
+    }
+}
+
+int h2gcn_hop_normalize(int64_t n, const int64_t* rowptr, const int32_t* colidx, int mode, const double* s_table,
+                        int64_t s_table_len, float* vals, void* stream) {
+    if (n < 0 || !rowptr || mode < 0 || mode > 2) return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad arguments to hop_normalize");
+    if (mode != 0 && (!s_table || s_table_len < 1)) return fail(H2GCN_ERR_INVALID_ARGUMENT, "scaling table missing");
+    if (n == 0) return H2GCN_OK;
+    if (!vals || !colidx) return fail(H2GCN_ERR_INVALID_ARGUMENT, "vals/colidx is NULL");
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 3) / 4, 256 * 32);
+    hipLaunchKernelGGL(normalize_pattern_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, rowptr, colidx, mode,
+                       s_table, vals);
+    H2GCN_HIP_TRY(hipGetLastError());
+    return H2GCN_OK;
+}
+
+}  // extern "C"

@@ -122,6 +122,16 @@ class HopPlan:
         return dict(n_rows=n_rows.value, n_cols=n_cols.value, nnz=nnz.value, n_long_segments=n_long.value,
                     has_transpose=bool(has_t.value))
 
+    def schedule(self, d: int, ld_src: Optional[int] = None, hops=None, adjoint: bool = False) -> dict:
+        """What a launch at feature width ``d`` (source row stride ``ld_src``, default contiguous) would do."""
+        L = _capi.lib()
+        sc, ns, pf, cp = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        ld = int(ld_src) if ld_src is not None else (self.n_selected(hops) * d if adjoint else d)
+        _capi.check(L.h2gcn_plan_schedule(self._handle, self._mask(hops), 1 if adjoint else 0, ld, int(d),
+                                          C.byref(sc), C.byref(ns), C.byref(pf), C.byref(cp)))
+        return dict(slice_cols=sc.value, n_slices=ns.value, index_prefetch=bool(pf.value),
+                    scratch_copy=bool(cp.value) and self.use_workspace)
+
     def _mask(self, hops) -> int:
         if hops is None:
             return 0

@@ -148,5 +148,9 @@ SHAPES = {
     "products": dict(n=2_400_000, nnz_per_hop=120_000_000, d=128),  # configs[3], configs[4]
     # not a BASELINE config: a low-degree stress shape (mean degree ~4, like Cora's 1-hop) for the short-row path
     "lowdeg": dict(n=8_000_000, nnz_per_hop=32_000_000, d=128),
+    # not BASELINE configs: gather working sets far beyond the 256 MiB Infinity Cache, to separate what HBM delivers
+    # from what the cache adds.  X = 8.2 GB (4.1 GB per 64-column slice):
+    "hbm16m": dict(n=16_000_000, nnz_per_hop=120_000_000, d=128),      # products' edge count, mean degree 7.5
+    "products_x6": dict(n=16_000_000, nnz_per_hop=800_000_000, d=128),  # products' degree distribution (mean 50)
 }
 SEED_A1, SEED_A2, SEED_X = 123, 124, 125

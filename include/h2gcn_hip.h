@@ -115,6 +115,13 @@ void h2gcn_plan_destroy(h2gcn_plan_t* plan);
 int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t* n_cols, int64_t* nnz,
                     int64_t* n_long_segments, int32_t* has_transpose);
 
+/* The schedule a launch of this plan would use for feature width d and source row stride ld_src (reports, tests):
+ * columns per slice of the slice-major schedule, number of slices, whether the index prefetch across segments is
+ * on, whether a forward launch with scratch would gather from a slice-major copy.  adjoint != 0 asks about
+ * h2gcn_spmm_hops_T_f32 (ld_src = ldg_row).  Any out pointer may be NULL. */
+int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, int64_t ld_src, int32_t d,
+                        int32_t* slice_cols, int32_t* n_slices, int32_t* index_prefetch, int32_t* scratch_copy);
+
 /*
  * Fused multi-hop aggregation, forward:
  *

@@ -52,6 +52,38 @@ __global__ __launch_bounds__(256) void copy_kernel(const float4* __restrict__ sr
                                     reinterpret_cast<float __attribute__((ext_vector_type(4)))*>(dst) + i);
 }
 
+using f4v = float __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void read_kernel(const f4v* __restrict__ src, size_t n, float* sink) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    f4v a = {0, 0, 0, 0}, b = a, c = a, e = a;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        a += __builtin_nontemporal_load(src + i);
+        b += __builtin_nontemporal_load(src + i + stride);
+        c += __builtin_nontemporal_load(src + i + 2 * stride);
+        e += __builtin_nontemporal_load(src + i + 3 * stride);
+    }
+    for (; i < n; i += stride) a += __builtin_nontemporal_load(src + i);
+    a += b + c + e;
+    const float t = a.x + a.y + a.z + a.w;
+    if (t == 12345.678f) *sink = t;  // never true for the memset pattern; keeps the loads alive
+}
+
+// read-only stream of `bytes`: what HBM delivers to a pure reader
+double run_read(size_t bytes) {
+    f4v* a; float* sink; CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&sink, 4)); CHECK(hipMemset(a, 1, bytes));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const size_t n = bytes / 16;
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(read_kernel, dim3(256 * 16), dim3(256), 0, 0, a, n, sink);
+    CHECK(hipEventRecord(e0));
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(read_kernel, dim3(256 * 16), dim3(256), 0, 0, a, n, sink);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    CHECK(hipFree(a)); CHECK(hipFree(sink));
+    return (double)bytes * reps / (ms * 1e-3) / 1e9;
+}
+
 // plain stream copy of `bytes` (read + write counted): the achievable HBM rate of this box
 double run_copy(size_t bytes) {
     float4 *a, *b; CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, bytes)); CHECK(hipMemset(a, 1, bytes)); CHECK(hipMemset(b, 0, bytes));
@@ -83,9 +115,10 @@ int point(size_t table_mib, int row_bytes) {
     }
     CHECK(hipFree(table)); CHECK(hipFree(out));
     const double c = run_copy(2ull << 30);
-    printf("{\"table_MiB\": %zu, \"row_bytes\": %d, \"gather_GBps\": %.1f, \"copy_GBps\": %.1f, "
+    const double r = run_read(4ull << 30);
+    printf("{\"table_MiB\": %zu, \"row_bytes\": %d, \"gather_GBps\": %.1f, \"copy_GBps\": %.1f, \"stream_read_GBps\": %.1f, "
            "\"what\": \"tools/gather_probe: random row gathers out of a table of this size (8 x 16-B loads in flight per lane); "
-           "copy = nontemporal stream copy of 2 GiB, read+write bytes\"}\n", table_mib, row_bytes, g, c);
+           "copy = nontemporal stream copy of 2 GiB, read+write bytes; stream_read = read-only pass over 4 GiB\"}\n", table_mib, row_bytes, g, c, r);
     return 0;
 }
 
