@@ -44,6 +44,10 @@ EXPORTED_SYMBOLS = (
     "h2gcn_plan_schedule",
     "h2gcn_spmm_workspace_bytes",
     "h2gcn_spmm_hops_ws_f32",
+    "h2gcn_ring_scratch_bytes",
+    "h2gcn_ring_count",
+    "h2gcn_ring_fill",
+    "h2gcn_hop_normalize",
     "h2gcn_xchg_create",
     "h2gcn_xchg_export",
     "h2gcn_xchg_connect",
@@ -132,6 +136,17 @@ def lib() -> C.CDLL:
         C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
         C.c_size_t, C.c_void_p,
     ]
+    L.h2gcn_ring_scratch_bytes.restype = C.c_size_t
+    L.h2gcn_ring_scratch_bytes.argtypes = [C.c_int64]
+    ring_common = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int,
+                   C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]
+    L.h2gcn_ring_count.restype = C.c_int
+    L.h2gcn_ring_count.argtypes = ring_common + [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_size_t, C.c_void_p]
+    L.h2gcn_ring_fill.restype = C.c_int
+    L.h2gcn_ring_fill.argtypes = ring_common + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.h2gcn_hop_normalize.restype = C.c_int
+    L.h2gcn_hop_normalize.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.h2gcn_xchg_create.restype = C.c_int
     L.h2gcn_xchg_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.h2gcn_xchg_export.restype = C.c_int

@@ -129,111 +129,160 @@ def row_normalize_features(features) -> sp.csr_matrix:
 
 
 # --------------------------------------------------------------------------------------------------------------
-# Device-side construction.  Same rings, same values, built with torch ops on the GPU:
-# neighbourhood growth is an expand -> sort -> unique over int64 keys (row * n + col), processed in row blocks
-# so that the expansion (sum over reached (i, j) of deg(j)) never exceeds a fixed budget.  The reference's host
-# SpGEMM `(A + I)^k` (scipy) is the scaling wall of its preprocessing (`_dataset.py:147-157`); this removes it for
+# Device-side construction: the same rings and values, built by hand-written HIP kernels
+# behind the C ABI (``h2gcn_ring_count`` / ``h2gcn_ring_fill`` / ``h2gcn_hop_normalize``, csrc/rings.hip).  A ring is a
+# boolean set expression over CSR patterns evaluated row by row in a two-level LDS bitmap -- the reference's host
+# SpGEMM ``(A + I)^k`` (scipy, ``_dataset.py:147-157``) is the scaling wall of its preprocessing; this removes it for
 # graphs whose exact-k-hop rings fit in HBM.  (At products scale the 2-hop ring itself is > 1e10 nonzeros.)
+# Host involvement: two scalar read-backs per ring (its nonzero count, to allocate it, and its largest row, to size
+# the scaling table) -- nothing proportional to the graph crosses PCIe.
 # --------------------------------------------------------------------------------------------------------------
 
-def _expand_keys(keys, rowptr, colidx, deg, n, budget):
-    """keys: sorted unique (i*n + j) of the current reach set.  Returns sorted unique keys of reach @ (A + I)."""
+def _pattern_args(patterns):
+    import ctypes as C
+
+    k = len(patterns)
+    arr_t = C.c_void_p * max(k, 1)
+    return k, arr_t(*[p[0].data_ptr() for p in patterns]), arr_t(*[p[1].data_ptr() for p in patterns])
+
+
+def ring_set_device(n: int, device, a=None, frontier=None, add=(), add_diag: bool = False, sub=(), sub_diag: bool = False):
+    """``out[i] = (U_{j in frontier[i]} a[j]  U  U add[i]  U {i}?) \\ (U sub[i] U {i}?)`` over CSR patterns
+    ``(rowptr int64 [n+1], colidx int32 [nnz])`` on ``device``; returns the result pattern with ascending columns.
+    See ``h2gcn_ring_count`` in include/h2gcn_hip.h."""
+    import ctypes as C
+
     import torch
 
-    out = []
-    cnt_all = deg[keys % n]
-    # split into blocks whose expansion stays under `budget`
-    csum = torch.cumsum(cnt_all, 0)
-    total = int(csum[-1]) if len(keys) else 0
-    start = 0
-    while start < len(keys):
-        base = int(csum[start - 1]) if start > 0 else 0
-        stop = int(torch.searchsorted(csum, torch.tensor(base + budget, device=keys.device), right=True))
-        stop = max(stop, start + 1)
-        k_blk = keys[start:stop]
-        cnt = cnt_all[start:stop]
-        i = torch.div(k_blk, n, rounding_mode="floor")
-        j = k_blk - i * n
-        tot = int(cnt.sum())
-        if tot > 0:
-            src = torch.repeat_interleave(torch.arange(len(k_blk), device=keys.device), cnt)
-            first = torch.cumsum(cnt, 0) - cnt
-            off = torch.arange(tot, device=keys.device) - first[src]
-            nb = colidx[rowptr[j[src]] + off].to(torch.int64)
-            out.append(torch.unique(i[src] * n + nb))
-        start = stop
-    del total
-    merged = torch.unique(torch.cat([keys] + out)) if out else keys
-    return merged
+    from . import _capi
+
+    L = _capi.lib()
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    a_rp, a_ci = a if a is not None else (None, None)
+    f_rp, f_ci = frontier if frontier is not None else (None, None)
+    n_add, add_rp, add_ci = _pattern_args(list(add))
+    n_sub, sub_rp, sub_ci = _pattern_args(list(sub))
+    with torch.cuda.device(device):
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        sb = int(L.h2gcn_ring_scratch_bytes(n))
+        scratch = torch.empty(sb, dtype=torch.uint8, device=device)
+        rowptr = torch.empty(n + 1, dtype=torch.int64, device=device)
+        nnz = C.c_int64()
+        common = (n, ptr(a_rp), ptr(a_ci), ptr(f_rp), ptr(f_ci), n_add, add_rp, add_ci, int(add_diag), n_sub, sub_rp, sub_ci,
+                  int(sub_diag))
+        _capi.check(L.h2gcn_ring_count(*common, ptr(rowptr), C.byref(nnz), ptr(scratch), sb, stream))
+        colidx = torch.empty(nnz.value, dtype=torch.int32, device=device)
+        if nnz.value:
+            _capi.check(L.h2gcn_ring_fill(*common, ptr(rowptr), ptr(colidx), ptr(scratch), sb, stream))
+    return rowptr, colidx
 
 
-def exact_hop_rings_device(rowptr, colidx, n: int, max_hop: int, budget: int = 1 << 27):
-    """Device version of :func:`exact_hop_rings`: list of sorted int64 key tensors (row * n + col), ring 0 = I."""
+def identity_pattern(n: int, device):
     import torch
 
+    return (torch.arange(n + 1, dtype=torch.int64, device=device), torch.arange(n, dtype=torch.int32, device=device))
+
+
+def exact_hop_rings_device(rowptr, colidx, n: int, max_hop: int):
+    """Device version of :func:`exact_hop_rings`: list of CSR patterns ``(rowptr, colidx)``; ring 0 = I.  Like the
+    reference (``_dataset.py:152-153``) the list ends early once reachability stops growing."""
     dev = rowptr.device
-    deg = (rowptr[1:] - rowptr[:-1])
-    eye = torch.arange(n, device=dev, dtype=torch.int64) * (n + 1)
-    reach = eye
-    rings = [eye]
-    for _ in range(int(max_hop)):
-        nxt = _expand_keys(reach, rowptr, colidx, deg, n, budget)
-        if nxt.numel() == reach.numel():
-            break
-        # ring = nxt \\ reach  (both sorted unique, reach is a subset of nxt)
-        pos = torch.searchsorted(reach, nxt)
-        pos = pos.clamp(max=reach.numel() - 1)
-        rings.append(nxt[reach[pos] != nxt])
-        reach = nxt
+    a = (rowptr, colidx)
+    rings = [identity_pattern(n, dev)]
+    for k in range(1, int(max_hop) + 1):
+        if k == 1:   # bin(I (A + I)) - I: the off-diagonal pattern of A
+            ring = ring_set_device(n, dev, add=[a], sub_diag=True)
+        else:        # expand the frontier ring_{k-1}, drop everything within distance < k
+            ring = ring_set_device(n, dev, a=a, frontier=rings[k - 1], sub=rings[1:k], sub_diag=True)
+        if ring[1].numel() == 0 and k > 1:   # reach did not grow (the reference's edge_sum test; its first ring is
+            break                            # always kept: edge_sum starts at 0, _dataset.py:145-153)
+        rings.append(ring)
     return rings
 
 
-def build_adj_norm_hops_device(adj_no_self_loops, adj_nhood: Sequence[str] = ("1", "2"),
-                               norm: str = SYM_NORMALIZED, device="cuda:0", budget: int = 1 << 27):
-    """Device-built ``adj_hops`` operands: ``(rowptr_list, colidx_list, vals_list, n)`` of CUDA tensors ready for
-    :class:`~h2gcn_amd.hops.HopPlan`.  Bit-identical to :func:`build_adj_norm_hops` + the fp32 cast: the degree
-    scalings are computed on the host with the same numpy call as the host path (length-n vectors), the products
-    in fp64 on the device (IEEE multiplication rounds identically everywhere)."""
+_S_TABLE_CACHE = {}
+
+
+def _scaling_table(norm: str, length: int, device):
+    """fp64 ``k^-1/2`` (SYM) / ``k^-1`` (RW) for k = 0 .. length-1 with ``inf -> 0`` -- the reference's own numpy
+    expression (``np.power(rowsum, -0.5)``, ``_dataset.py:115-123``), evaluated on the possible row sums."""
     import torch
 
-    a = sp.csr_matrix(adj_no_self_loops)
-    a.sum_duplicates()
-    a.sort_indices()
-    a.eliminate_zeros()
-    n = a.shape[0]
-    if a.shape[0] != a.shape[1]:
-        raise ValueError(f"adjacency must be square, got {a.shape}")
-    rowptr = torch.from_numpy(a.indptr.astype(np.int64)).to(device)
-    colidx = torch.from_numpy(a.indices.astype(np.int64)).to(device)
+    key = (norm, str(device))
+    tab = _S_TABLE_CACHE.get(key)
+    if tab is None or tab.numel() < length:
+        size = max(length, 1024, 2 * (tab.numel() if tab is not None else 0))
+        k = np.arange(size, dtype=np.float64)
+        with np.errstate(divide="ignore"):
+            s = np.power(k, -0.5 if norm == SYM_NORMALIZED else -1.0)
+        s[np.isinf(s)] = 0.0
+        tab = torch.from_numpy(s).to(device)
+        _S_TABLE_CACHE[key] = tab
+    return tab
+
+
+def normalize_pattern_device(pattern, n: int, norm: str):
+    """fp32 values of the normalised hop matrix for a square CSR pattern (``h2gcn_hop_normalize``)."""
+    import ctypes as C
+
+    import torch
+
+    from . import _capi
+
+    rowptr, colidx = pattern
+    dev = rowptr.device
+    vals = torch.empty(colidx.numel(), dtype=torch.float32, device=dev)
+    mode = {ORDINARY: 0, SYM_NORMALIZED: 1, RW_NORMALIZED: 2}.get(norm)
+    if mode is None:
+        raise ValueError(f"unknown normalisation {norm!r}")
+    if colidx.numel() == 0:
+        return vals
+    tab = None
+    if mode != 0:
+        max_deg = int((rowptr[1:] - rowptr[:-1]).max())
+        tab = _scaling_table(norm, max_deg + 1, dev)
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _capi.check(_capi.lib().h2gcn_hop_normalize(n, C.c_void_p(rowptr.data_ptr()), C.c_void_p(colidx.data_ptr()), mode,
+                                                    C.c_void_p(tab.data_ptr()) if tab is not None else None,
+                                                    tab.numel() if tab is not None else 0, C.c_void_p(vals.data_ptr()), stream))
+    return vals
+
+
+def build_adj_norm_hops_device(adj_no_self_loops, adj_nhood: Sequence[str] = ("1", "2"),
+                               norm: str = SYM_NORMALIZED, device="cuda:0"):
+    """Device-built ``adj_hops`` operands: ``(rowptr_list, colidx_list, vals_list, n)`` of CUDA tensors ready for
+    :class:`~h2gcn_amd.hops.HopPlan`.  Bit-identical to :func:`build_adj_norm_hops` + the fp32 cast.  The adjacency
+    may be a scipy matrix (uploaded once) or a ``(rowptr int64, colidx int32)`` pair already on the device."""
+    import torch
+
+    if isinstance(adj_no_self_loops, tuple):
+        rowptr, colidx = adj_no_self_loops
+        n = rowptr.numel() - 1
+        device = rowptr.device
+    else:
+        a = sp.csr_matrix(adj_no_self_loops)
+        a.sum_duplicates()
+        a.sort_indices()
+        a.eliminate_zeros()
+        n = a.shape[0]
+        if a.shape[0] != a.shape[1]:
+            raise ValueError(f"adjacency must be square, got {a.shape}")
+        rowptr = torch.from_numpy(a.indptr.astype(np.int64)).to(device)
+        colidx = torch.from_numpy(a.indices.astype(np.int32)).to(device)
+    device = torch.device(device)
     groups = parse_adj_nhood(adj_nhood)
-    rings = exact_hop_rings_device(rowptr, colidx, n, max(max(g) for g in groups), budget)
+    rings = exact_hop_rings_device(rowptr, colidx, n, max(max(g) for g in groups))
     rps, cis, vas = [], [], []
     for g in groups:
         missing = [i for i in g if i >= len(rings)]
         if missing:
             raise ValueError(f"hop {missing[0]} requested but the graph's reachability saturates after {len(rings) - 1} hops")
-        keys = rings[g[0]] if len(g) == 1 else torch.sort(torch.cat([rings[i] for i in g]))[0]
-        rows = torch.div(keys, n, rounding_mode="floor")
-        cols = keys - rows * n
-        counts = torch.bincount(rows, minlength=n)
-        rp = torch.zeros(n + 1, dtype=torch.int64, device=keys.device)
-        rp[1:] = torch.cumsum(counts, 0)
-        deg_host = counts.cpu().numpy().astype(np.float64)
-        with np.errstate(divide="ignore"):
-            if norm == SYM_NORMALIZED:
-                s = np.power(deg_host, -0.5)
-                s[np.isinf(s)] = 0.0
-                st = torch.from_numpy(s).to(keys.device)
-                vals = (st[rows] * 1.0) * st[cols]
-            elif norm == RW_NORMALIZED:
-                s = np.power(deg_host, -1.0)
-                s[np.isinf(s)] = 0.0
-                vals = torch.from_numpy(s).to(keys.device)[rows] * 1.0
-            elif norm == ORDINARY:
-                vals = torch.ones(len(keys), dtype=torch.float64, device=keys.device)
-            else:
-                raise ValueError(f"unknown normalisation {norm!r}")
-        rps.append(rp)
-        cis.append(cols.to(torch.int32).contiguous())
-        vas.append(vals.to(torch.float32).contiguous())
+        if len(g) == 1:
+            pat = rings[g[0]]
+        else:  # merged group: union of the (disjoint) member rings, reference ``sum(...)`` (_dataset.py:571-572)
+            pat = ring_set_device(n, device, add=[rings[i] for i in g if i != 0], add_diag=0 in g)
+        rps.append(pat[0])
+        cis.append(pat[1])
+        vas.append(normalize_pattern_device(pat, n, norm))
     return rps, cis, vas, n

@@ -174,6 +174,48 @@ int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const flo
                           int64_t ldg_hop, int32_t d, float* dX_dev, int64_t ldx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Operand construction on the device: exact-k-hop neighbourhood rings and their normalisation -- the step that
+ * FEEDS the aggregation.  Stands in for TransformSPAdj.nhoodSplit (reference h2gcn/datasets/_dataset.py:138-158:
+ * `mt <- bin(mt @ (A + I))`, ring_k = mt_k - mt_{k-1}, a host SpGEMM in scipy) and TransformSPAdj.normalize
+ * (:109-124).  A ring is a SET expression over CSR patterns, evaluated row by row in a two-level LDS bitmap
+ * (h2gcn_amd/csrc/rings.hip):
+ *
+ *     out[i] = ( U_{j in F[i]} A[j]  U  U_p ADD_p[i]  U  ({i} if add_diag) )  \  ( U_q SUB_q[i]  U  ({i} if sub_diag) )
+ *
+ *   ring_k (k >= 1):  F = ring_{k-1} (ring_0 = I, i.e. F[i] = {i}; for k = 1 simply pass F = I or use ring_1 = A),
+ *                     SUB = ring_1 .. ring_{k-1}, sub_diag = 1
+ *   merged group "0,1" of --adj_nhood (getTensors, :560-572):  no F, ADD = {ring_1}, add_diag = 1
+ *
+ * All patterns are n x n CSR (int64 rowptr, int32 colidx ascending, no values); outputs have ascending columns.
+ * Two passes: h2gcn_ring_count writes out_rowptr[0..n] (row pointers of the result) and returns the number of
+ * nonzeros (it synchronises the stream -- the caller has to allocate out_colidx); h2gcn_ring_fill, called with the
+ * SAME inputs, writes the columns.  `scratch` is h2gcn_ring_scratch_bytes(n) bytes of device memory.
+ * F == NULL (f_rowptr NULL) means "no expansion"; a_* may then be NULL as well.
+ */
+size_t h2gcn_ring_scratch_bytes(int64_t n);
+int h2gcn_ring_count(int64_t n, const int64_t* a_rowptr_dev, const int32_t* a_colidx_dev,
+                     const int64_t* f_rowptr_dev, const int32_t* f_colidx_dev,
+                     int n_add, const int64_t* const* add_rowptr_dev, const int32_t* const* add_colidx_dev, int add_diag,
+                     int n_sub, const int64_t* const* sub_rowptr_dev, const int32_t* const* sub_colidx_dev, int sub_diag,
+                     int64_t* out_rowptr_dev, int64_t* nnz_out, void* scratch_dev, size_t scratch_bytes, void* stream);
+int h2gcn_ring_fill(int64_t n, const int64_t* a_rowptr_dev, const int32_t* a_colidx_dev,
+                    const int64_t* f_rowptr_dev, const int32_t* f_colidx_dev,
+                    int n_add, const int64_t* const* add_rowptr_dev, const int32_t* const* add_colidx_dev, int add_diag,
+                    int n_sub, const int64_t* const* sub_rowptr_dev, const int32_t* const* sub_colidx_dev, int sub_diag,
+                    const int64_t* out_rowptr_dev, int32_t* out_colidx_dev, void* scratch_dev, size_t scratch_bytes,
+                    void* stream);
+/*
+ * Values of a hop matrix given as a square CSR PATTERN (every stored entry is 1, as nhoodSplit produces):
+ *   mode 0 ORDINARY: 1;  mode 1 SYM: fp32((s[deg_i] * 1.0) * s[deg_j]);  mode 2 RW: fp32(s[deg_i] * 1.0)
+ * with deg = the row lengths of THIS matrix (reference: D = rowsum(A_k) of that hop matrix, :115-123) and
+ * s_table[k] = the fp64 scaling of a row with k entries (k^-1/2 resp. k^-1, inf -> 0), supplied by the caller -- the
+ * Python front end computes it with the reference's own numpy call, which keeps the fp64 products and the fp32 cast
+ * of sparse2Tensor (:528-535) bit-identical to the reference.  s_table_len > max row length.
+ */
+int h2gcn_hop_normalize(int64_t n, const int64_t* rowptr_dev, const int32_t* colidx_dev, int mode,
+                        const double* s_table_dev, int64_t s_table_len, float* vals_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Row-shard exchange between the GPUs of one node (no counterpart in the reference: it is single-process,
  * single-device -- SURVEY.md 8(e) adds the row partition).  Before a hop aggregation every rank needs the whole
  * embedding X[N, d] while it owns only X[rows_p, :]; this object performs that all-gather WITHOUT a collective

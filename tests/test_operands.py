@@ -50,21 +50,3 @@ def test_empty_rows_scale_to_zero():
         assert np.isfinite(h.data).all() and h[2].nnz == 0
 
 
-@pytest.mark.parametrize("name", ["cora", "citeseer"])
-def test_device_ring_builder_algorithm_matches_host(name):
-    """build_adj_norm_hops_device (expand/sort/unique over int64 keys; run here with torch on the CPU device and a
-    tiny expansion budget so that the row-blocking is exercised) == the scipy builder, bit for bit."""
-    g = load_planetoid_golden(name)
-    adj = po.remove_self_loops(g["adj_raw"])
-    for norm in (po.SYM_NORMALIZED, po.RW_NORMALIZED):
-        for nh in (("1", "2"), ("0,1", "2"), ("2",)):
-            rps, cis, vas, n = po.build_adj_norm_hops_device(adj, nh, norm, "cpu", budget=5000)
-            host = po.build_adj_norm_hops(adj, nh, norm)
-            assert n == g["n"] and len(host) == len(rps)
-            for k, h in enumerate(host):
-                h = sp.csr_matrix(h); h.sort_indices()
-                assert np.array_equal(rps[k].numpy(), h.indptr) and np.array_equal(cis[k].numpy(), h.indices)
-                assert np.array_equal(vas[k].numpy(), h.data.astype(np.float32))
-    _same(sp.csr_matrix((vas[0].numpy(), cis[0].numpy(), rps[0].numpy()), shape=(n, n)), g["hop2_rw"])
-    with pytest.raises(ValueError):
-        po.build_adj_norm_hops_device(sp.csr_matrix(np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]], dtype=np.float32)), ("3",), device="cpu")

@@ -1,0 +1,109 @@
+"""GPU suite: exact-k-hop ring construction and normalisation by the HIP kernels of csrc/rings.hip (through the C
+ABI) against the host builder / the fixtures produced by the reference's own `nhoodSplit` + `normalize`
+(tests/golden/*_operands.npz).  Integer/bit work: everything is compared bit for bit."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import load_planetoid_golden, load_syn_products_golden
+from h2gcn_amd import operands as po
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _same_operands(rps, cis, vas, host):
+    assert len(host) == len(rps)
+    for k, h in enumerate(host):
+        h = sp.csr_matrix(h)
+        h.sort_indices()
+        assert np.array_equal(rps[k].cpu().numpy(), h.indptr), k
+        assert np.array_equal(cis[k].cpu().numpy(), h.indices), k
+        assert np.array_equal(vas[k].cpu().numpy(), h.data.astype(np.float32)), k
+
+
+@pytest.mark.parametrize("name", ["cora", "citeseer"])
+def test_planetoid_rings_equal_reference_fixtures(name):
+    g = load_planetoid_golden(name)
+    adj = po.remove_self_loops(g["adj_raw"])
+    for norm in (po.SYM_NORMALIZED, po.RW_NORMALIZED, po.ORDINARY):
+        for nh in (("1", "2"), ("0,1", "2"), ("2",), ("0",), ("0,1,2",)):
+            rps, cis, vas, n = po.build_adj_norm_hops_device(adj, nh, norm, DEV)
+            assert n == g["n"]
+            _same_operands(rps, cis, vas, po.build_adj_norm_hops(adj, nh, norm))
+    # directly against what the reference's own code produced (fixtures hold its fp32-cast outputs)
+    rps, cis, vas, n = po.build_adj_norm_hops_device(adj, ("1", "2"), po.SYM_NORMALIZED, DEV)
+    for k, key in enumerate(("hop1_sym", "hop2_sym")):
+        want = g[key]
+        assert np.array_equal(cis[k].cpu().numpy(), want.indices) and np.array_equal(vas[k].cpu().numpy(), want.data)
+    rps, cis, vas, n = po.build_adj_norm_hops_device(adj, ("0,1",), po.SYM_NORMALIZED, DEV)
+    assert np.array_equal(vas[0].cpu().numpy(), g["hop01_sym"].data) and np.array_equal(cis[0].cpu().numpy(), g["hop01_sym"].indices)
+    nnz = [int(r[1].numel()) for r in po.exact_hop_rings_device(torch.from_numpy(adj.indptr.astype(np.int64)).to(DEV),
+                                                                torch.from_numpy(adj.indices.astype(np.int32)).to(DEV), n, 2)]
+    assert nnz == list(g["split_nnz"])
+
+
+def test_saturating_reachability_and_self_loops():
+    path = sp.csr_matrix(np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]], dtype=np.float32))
+    with pytest.raises(ValueError):
+        po.build_adj_norm_hops_device(path, ("3",), device=DEV)
+    rp = torch.from_numpy(path.indptr.astype(np.int64)).to(DEV)
+    ci = torch.from_numpy(path.indices.astype(np.int32)).to(DEV)
+    rings = po.exact_hop_rings_device(rp, ci, 3, 5)
+    assert [r[1].cpu().tolist() for r in rings] == [[0, 1, 2], [1, 0, 2, 1], [2, 0]]        # like the reference: list ends early
+    # self loops in A do not leak into ring 1 (bin(A + I) - I)
+    loops = sp.csr_matrix(np.array([[1, 1, 0], [1, 1, 1], [0, 1, 0]], dtype=np.float32))
+    r1 = po.ring_set_device(3, torch.device(DEV), add=[(torch.from_numpy(loops.indptr.astype(np.int64)).to(DEV),
+                                                      torch.from_numpy(loops.indices.astype(np.int32)).to(DEV))], sub_diag=True)
+    assert r1[1].cpu().tolist() == [1, 0, 2, 1] and r1[0].cpu().tolist() == [0, 1, 3, 4]
+
+
+@pytest.mark.parametrize("n,deg,hops", [(1, 0, 2), (64, 3, 3), (5000, 4, 3), (33000, 2.5, 4), (20000, 30, 2)])
+def test_random_graphs_equal_host_spgemm(n, deg, hops):
+    rng = np.random.default_rng(n)
+    m = int(n * deg / 2)
+    r, c = rng.integers(0, n, m), rng.integers(0, n, m)
+    a = sp.csr_matrix((np.ones(2 * m, dtype=np.float32), (np.r_[r, c], np.r_[c, r])), shape=(n, n))
+    a = po.remove_self_loops(a)
+    a.data[:] = 1
+    host = po.exact_hop_rings(a, hops)
+    a.sort_indices()
+    rings = po.exact_hop_rings_device(torch.from_numpy(a.indptr.astype(np.int64)).to(DEV),
+                                      torch.from_numpy(a.indices.astype(np.int32)).to(DEV), n, hops)
+    assert len(rings) == len(host)
+    for k, h in enumerate(host):
+        h = sp.csr_matrix(h)
+        h.sort_indices()
+        assert np.array_equal(rings[k][0].cpu().numpy(), h.indptr) and np.array_equal(rings[k][1].cpu().numpy(), h.indices), k
+
+
+def test_syn_products_two_hop_ring():
+    a, _, _ = load_syn_products_golden()
+    adj = po.remove_self_loops(a)
+    rps, cis, vas, n = po.build_adj_norm_hops_device(adj, ["1", "2"], "sym", DEV)
+    _same_operands(rps, cis, vas, po.build_adj_norm_hops(adj, ["1", "2"], "sym"))
+    assert cis[1].numel() > 2_000_000        # the 2.8M-nonzero ring of SURVEY.md config 2
+
+
+def test_more_than_2_20_columns_uses_the_global_bitmap():
+    """n > 1 Mi columns: level 0 of the bitmap lives in per-workgroup global slabs (level 1 stays in LDS)."""
+    n = (1 << 20) + 12345
+    rng = np.random.default_rng(3)
+    m = 2 * n
+    r, c = rng.integers(0, n, m), rng.integers(0, n, m)
+    a = sp.csr_matrix((np.ones(2 * m, dtype=np.float32), (np.r_[r, c], np.r_[c, r])), shape=(n, n))
+    a = po.remove_self_loops(a)
+    a.data[:] = 1
+    a.sort_indices()
+    host = po.exact_hop_rings(a, 2)
+    rings = po.exact_hop_rings_device(torch.from_numpy(a.indptr.astype(np.int64)).to(DEV),
+                                      torch.from_numpy(a.indices.astype(np.int32)).to(DEV), n, 2)
+    for k in (1, 2):
+        h = sp.csr_matrix(host[k])
+        h.sort_indices()
+        assert np.array_equal(rings[k][0].cpu().numpy(), h.indptr) and np.array_equal(rings[k][1].cpu().numpy(), h.indices)
+    vals = po.normalize_pattern_device(rings[2], n, po.SYM_NORMALIZED).cpu().numpy()
+    want = sp.csr_matrix(po.normalize_hop(host[2], po.SYM_NORMALIZED))
+    want.sort_indices()
+    assert np.array_equal(vals, want.data.astype(np.float32))
