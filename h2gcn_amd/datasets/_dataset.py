@@ -200,6 +200,73 @@ def _sharded_tensors(self, device, adj_norm_hops, norm, shard):
 PlanetoidData._get_tensors_sharded = _sharded_tensors
 
 
+def read_generated_graph(directory, graph_name: str):
+    """The graph generator's on-disk pair (reference ``experiments/h2gcn/modules/graphgen.py:37-58``):
+    ``<graph_name>.graph`` = pickled ``nx.to_dict_of_lists(G)`` and ``<graph_name>.ally`` = pickled one-hot label
+    array ``[n, numClass]`` (class = node colour - 1).  When only ``<graph_name>.gpickle.gz`` exists (``:60-66``, the
+    pickled networkx graph with the ``color`` node attribute) it is read instead.  Returns
+    ``(adjacency csr float32 [n, n], labels_onehot float [n, C])``."""
+    import gzip
+
+    base = Path(directory)
+    g_file, y_file, nx_file = (base / f"{graph_name}{ext}" for ext in (".graph", ".ally", ".gpickle.gz"))
+    if g_file.exists() and y_file.exists():
+        graph = _load_pickle(g_file)
+        ally = np.asarray(_load_pickle(y_file))
+    elif nx_file.exists():
+        with gzip.open(nx_file, "rb") as f:
+            G = pickle.load(f)
+        nodes = sorted(G.nodes())
+        if nodes != list(range(len(nodes))):
+            raise ValueError(f"{nx_file}: nodes must be labelled 0..n-1")
+        graph = {u: list(G.adj[u]) for u in nodes}
+        colours = np.array([G.nodes[u].get("color", 0) for u in nodes], dtype=np.int64)
+        ally = np.zeros((len(nodes), int(colours.max())), dtype=np.float64)
+        has = colours > 0
+        ally[np.nonzero(has)[0], colours[has] - 1] = 1.0
+    else:
+        raise FileNotFoundError(f"neither {g_file} + {y_file} nor {nx_file} exists")
+    if sorted(graph) != list(range(len(graph))):
+        raise ValueError(f"{g_file}: nodes must be labelled 0..n-1")
+    if ally.ndim != 2 or ally.shape[0] != len(graph):
+        raise ValueError(f"{y_file}: label array has shape {ally.shape}, the graph has {len(graph)} nodes")
+    return adjacency_from_neighbour_lists({u: graph[u] for u in range(len(graph))}), ally
+
+
+class GeneratedGraphData(PlanetoidData):
+    """A generator graph (``.graph`` + ``.ally``) as a dataset.  The generator stores no features and no splits -- the
+    reference attaches ogbn-products features and splits in a later signac stage (``feature_generation.py``), neither
+    of which exists offline -- so features are either given (``features``: ``[n, F]`` array / scipy matrix) or drawn
+    class-conditionally (unit-variance Gaussians around random class centres, ``feature_seed``), and the split is a
+    seeded random ``train_frac / val_frac / rest`` partition of the labelled nodes."""
+
+    def __init__(self, graph_name: str, dataset_path, features=None, feature_dim: int = 100, feature_seed: int = 0,
+                 split_seed: int = 0, train_frac: float = 0.25, val_frac: float = 0.25):
+        self.dataset_str, self.dataset_path = graph_name, str(dataset_path)
+        self.val_size = None
+        self.preprocessed_feature = False
+        adj, labels = read_generated_graph(dataset_path, graph_name)
+        n = adj.shape[0]
+        valid = labels.sum(1) > 0
+        self.non_valid_samples = set(np.where(~valid)[0].tolist())
+        if features is None:
+            rng = np.random.default_rng(feature_seed)
+            centres = rng.standard_normal((labels.shape[1], feature_dim))
+            features = (labels @ centres + rng.standard_normal((n, feature_dim))).astype(np.float32)
+        features = sp.csr_matrix(features)
+        if features.shape[0] != n:
+            raise ValueError(f"features have {features.shape[0]} rows, the graph has {n} nodes")
+        order = np.random.default_rng(split_seed).permutation(np.nonzero(valid)[0])
+        n_train, n_val = int(round(train_frac * len(order))), int(round(val_frac * len(order)))
+        masks = [np.zeros(n, dtype=bool) for _ in range(3)]
+        masks[0][order[:n_train]] = True
+        masks[1][order[n_train:n_train + n_val]] = True
+        masks[2][order[n_train + n_val:]] = True
+        self.sparse_adj, self.features, self.y_all = adj, features, labels
+        self.train_mask, self.val_mask, self.test_mask = masks
+        self.y_train, self.y_val, self.y_test = (np.where(m[:, None], labels, 0.0) for m in masks)
+
+
 def export_planetoid(path, name, adj, features, labels_onehot, n_train: int, test_ids: Sequence[int],
                      n_allx: Optional[int] = None):
     """Write a graph in the planetoid on-disk format (inverse of the loader; used to round-trip fixtures and to

@@ -22,6 +22,10 @@ Fixtures
 * dsl_parse.json         parse_network_setup() output for the network strings used by the reference configs.
 * cora_layer_outputs.npz r1 / r2 of H2GCN-2 on the golden Cora operands (row subset + fp64 column sums), via scipy.
 * syn_products.npz       one graph from the reference generator (n=10000, 10 classes, m=6, h=0.2) as CSR.
+* generated/syn_small.{graph,ally,gpickle.gz} + syn_small_expected.npz
+                         FILES WRITTEN BY THE REFERENCE'S GENERATOR itself (graphgen.py save_graph / save_y /
+                         save_nx_graph) for one n=400, 5-class, h=0.3 graph, plus the adjacency the reference's loader
+                         helper (`PlanetoidData.graphDict2Adj`) derives from the .graph file.
 * glue_cora.npz/.json    the reference's OWN `_layers.py` / `H2GCN.py` / `_metrics.py` executed under a numpy/scipy
                          stand-in for TensorFlow (tests/golden/_tf_standin.py) on the golden Cora operands with
                          regenerable weights (conftest.golden_weight): logits, every tagged activation (row subset +
@@ -299,6 +303,7 @@ def main():
     dsl_fixture()
     layer_output_fixture()
     glue_fixture()
+    make_syn_small(syn_fixture(), ref)
     if a.syn:
         make_syn(syn_fixture())
 
@@ -323,6 +328,35 @@ def make_syn(mod):
     np.savez_compressed(HERE / "syn_products.npz", indptr=A.indptr.astype(np.int64), indices=A.indices.astype(np.int32),
                         labels=labels, homophily=np.float64(homophily), seed=np.int64(seed))
     print("syn graph: nnz", A.nnz, "edge homophily", homophily)
+
+
+def make_syn_small(mod, ref):
+    """A small graph from the reference generator, WRITTEN TO DISK BY THE GENERATOR'S OWN save_* methods: fixtures for
+    the reader of the generator format (graphgen.py:37-66)."""
+    import gzip
+    import pickle
+
+    import networkx as nx
+
+    out = HERE / "generated"
+    out.mkdir(exist_ok=True)
+    seed = 4242
+    np.random.seed(seed)
+    mod.random_state = np.random.RandomState(seed)
+    n, n_class, m, h = 400, 5, 3, 0.3
+    gen = mod.MixhopGraphGenerator([n // n_class] * n_class, "circularDist", heteroWeightsExponent=1.0)
+    G = gen(n, m, m * n_class, h)
+    nx.write_gpickle = lambda g, path: pickle.dump(g, gzip.open(path, "wb"))   # removed from networkx 3
+    mod.nx.write_gpickle = nx.write_gpickle
+    gen.save_graph(G, str(out), "syn_small")
+    gen.save_y(G, str(out), "syn_small")
+    gen.save_nx_graph(G, str(out), "syn_small")
+    graph = pickle.load(open(out / "syn_small.graph", "rb"))
+    A = sp.csr_matrix(ref.PlanetoidData.graphDict2Adj(graph)).astype(np.float32)   # the reference's own conversion
+    A.sort_indices()
+    np.savez_compressed(out / "syn_small_expected.npz", indptr=A.indptr.astype(np.int64), indices=A.indices.astype(np.int32),
+                        data=A.data, labels=np.array([G.nodes[v]["color"] - 1 for v in range(n)], dtype=np.int8))
+    print("syn_small: nnz", A.nnz)
 
 
 if __name__ == "__main__":

@@ -157,3 +157,32 @@ def test_dense_features_are_not_wrapped_as_sparse_operands(tmp_path):
     f_sparse = sp.random(50, 40, 0.05, format="csr", random_state=0, dtype=np.float32)
     with pytest.raises(ValueError, match="GPU"):   # sparse -> HopPlan, which refuses CPU tensors (no fallback)
         dummy._feature_operand(f_sparse, "cpu", True)
+
+
+# ------------------------------------------------------------------ the generator's on-disk format (graphgen.py:37-66)
+def test_reader_of_the_generator_format_matches_reference_conversion(tmp_path):
+    """tests/golden/generated/syn_small.{graph,ally,gpickle.gz} were WRITTEN BY THE REFERENCE'S GENERATOR (save_graph /
+    save_y / save_nx_graph, imported in place by make_golden.py); syn_small_expected.npz holds the adjacency the
+    reference's own graphDict2Adj derives from the .graph file.  Both the pickle pair and the gzip'd networkx pickle
+    must give exactly that graph."""
+    import shutil
+
+    import numpy as np
+
+    from conftest import GOLDEN
+    from h2gcn_amd.datasets._dataset import GeneratedGraphData, read_generated_graph
+
+    z = np.load(GOLDEN / "generated" / "syn_small_expected.npz")
+    adj, ally = read_generated_graph(GOLDEN / "generated", "syn_small")
+    assert np.array_equal(adj.indptr, z["indptr"]) and np.array_equal(adj.indices, z["indices"]) and np.array_equal(adj.data, z["data"])
+    assert ally.shape == (400, 5) and np.array_equal(ally.argmax(1), z["labels"]) and (ally.sum(1) == 1).all()
+    # only the networkx pickle present
+    shutil.copy(GOLDEN / "generated" / "syn_small.gpickle.gz", tmp_path / "only_nx.gpickle.gz")
+    adj2, ally2 = read_generated_graph(tmp_path, "only_nx")
+    assert (adj2 != adj).nnz == 0 and np.array_equal(ally2, ally)
+    data = GeneratedGraphData("syn_small", GOLDEN / "generated", feature_dim=16, feature_seed=1, split_seed=2)
+    assert data.num_samples == 400 and data.num_labels == 5 and data.features.shape == (400, 16)
+    masks = data.train_mask.astype(int) + data.val_mask.astype(int) + data.test_mask.astype(int)
+    assert (masks == 1).all() and data.train_mask.sum() == 100 and data.val_mask.sum() == 100
+    with __import__("pytest").raises(FileNotFoundError):
+        read_generated_graph(tmp_path, "missing")

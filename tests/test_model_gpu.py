@@ -260,3 +260,28 @@ def test_hipgraph_replay_matches_eager_training(tmp_path, capsys):
         assert abs(stats_graph[k] - stats_eager[k]) <= 1e-4, (k, stats_graph[k], stats_eager[k])
     out = capsys.readouterr().out
     assert "capture unavailable" not in out
+
+
+def test_entry_point_trains_on_a_generator_format_graph(capsys):
+    """`run_experiments H2GCN generated ...`: the reference generator's own output files (tests/golden/generated) as
+    the dataset -- hop rings built on the device, class-conditional synthetic features (dense -> GEMM embedding),
+    `--no_feature_normalize` as in the syn-products configs; the model fits the training nodes."""
+    from conftest import GOLDEN
+    from h2gcn_amd import run_experiments
+
+    args = run_experiments.main(["H2GCN", "generated", "--dataset", "syn_small", "--dataset_path", str(GOLDEN / "generated"),
+                                 "--feature_dim", "32", "--no_feature_normalize", "--epochs", "60", "--random_seed", "3",
+                                 "--json_stats"])
+    out = capsys.readouterr().out
+    assert "===> Dataset loaded: syn_small" in out and '"epoch": 60' in out
+    best = args.objects["best_val_stats"]
+    assert best["train_acc"] >= 0.9 and best["val_acc"] >= 0.5
+    assert args.objects["tensors"]["adj_hops"].n_rows == 400
+
+
+def test_zero_epochs_reports_the_untrained_model(tmp_path, capsys):
+    from h2gcn_amd import run_experiments
+
+    _cora_files(tmp_path)
+    args = run_experiments.main(["H2GCN", "planetoid", "--dataset", "ind.cora", "--dataset_path", str(tmp_path), "--epochs", "0"])
+    assert args.objects["best_val_stats"]["epoch"] == 0 and "Best performance:" in capsys.readouterr().out
