@@ -30,6 +30,7 @@ XCHG_COPY_KERNEL = 1
 PLAN_BUILD_TRANSPOSE = 0x1
 PLAN_SKIP_VALIDATION = 0x2
 PLAN_HOST_TRANSPOSE = 0x4
+PLAN_KEEP_PERMUTATION = 0x8
 
 #: every symbol include/h2gcn_hip.h declares (tests check the built library exports all of them)
 EXPORTED_SYMBOLS = (
@@ -39,11 +40,12 @@ EXPORTED_SYMBOLS = (
     "h2gcn_plan_create",
     "h2gcn_plan_destroy",
     "h2gcn_plan_info",
+    "h2gcn_plan_set_values",
     "h2gcn_spmm_hops_f32",
     "h2gcn_spmm_hops_T_f32",
     "h2gcn_plan_schedule",
     "h2gcn_spmm_workspace_bytes",
-    "h2gcn_spmm_hops_ws_f32",
+    "h2gcn_spmm_hops_opts_f32",
     "h2gcn_ring_scratch_bytes",
     "h2gcn_ring_count",
     "h2gcn_ring_fill",
@@ -67,6 +69,19 @@ class PlanOpts(C.Structure):
         ("variant", C.c_int32),
         ("slice_cols", C.c_int32),
         ("reserved", C.c_int32 * 2),
+    ]
+
+
+LAUNCH_RELU = 0x1
+
+
+class LaunchOpts(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_size_t),
+        ("bias", C.c_void_p),
     ]
 
 
@@ -114,6 +129,8 @@ def lib() -> C.CDLL:
     ]
     L.h2gcn_plan_destroy.restype = None
     L.h2gcn_plan_destroy.argtypes = [C.c_void_p]
+    L.h2gcn_plan_set_values.restype = C.c_int
+    L.h2gcn_plan_set_values.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.h2gcn_plan_info.restype = C.c_int
     L.h2gcn_plan_info.argtypes = [
         C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
@@ -131,10 +148,10 @@ def lib() -> C.CDLL:
     L.h2gcn_plan_schedule.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int64, C.c_int32] + [C.POINTER(C.c_int32)] * 4
     L.h2gcn_spmm_workspace_bytes.restype = C.c_size_t
     L.h2gcn_spmm_workspace_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_int32]
-    L.h2gcn_spmm_hops_ws_f32.restype = C.c_int
-    L.h2gcn_spmm_hops_ws_f32.argtypes = [
-        C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
-        C.c_size_t, C.c_void_p,
+    L.h2gcn_spmm_hops_opts_f32.restype = C.c_int
+    L.h2gcn_spmm_hops_opts_f32.argtypes = [
+        C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64,
+        C.POINTER(LaunchOpts), C.c_void_p,
     ]
     L.h2gcn_ring_scratch_bytes.restype = C.c_size_t
     L.h2gcn_ring_scratch_bytes.argtypes = [C.c_int64]

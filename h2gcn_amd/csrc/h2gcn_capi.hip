@@ -62,6 +62,7 @@ struct HopOperand {  // one CSR, device pointers
     const float* vals = nullptr;
     int64_t nnz = 0;
     std::vector<int64_t> long_rows;  // rows whose segment has >= long_row_threshold nonzeros, ascending
+    const uint32_t* perm = nullptr;  // adjoint operands built with H2GCN_PLAN_KEEP_PERMUTATION: source entry of entry i
 };
 
 struct LongList {
@@ -93,7 +94,8 @@ struct h2gcn_plan {
 namespace h2gcn {
 int transpose_csr_device(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                          const float* vals, int64_t** t_rowptr_out, int32_t** t_colidx_out, float** t_vals_out,
-                         hipStream_t stream, std::string* err);
+                         uint32_t** perm_out_keep, hipStream_t stream, std::string* err);
+void permute_values(const uint32_t* perm, const float* vals, int64_t nnz, float* t_vals, hipStream_t stream);
 }
 
 namespace {
@@ -400,16 +402,23 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
                 int64_t* t_rp = nullptr;
                 int32_t* t_ci = nullptr;
                 float* t_va = nullptr;
+                uint32_t* t_perm = nullptr;
+                const bool keep_perm = (o.flags & H2GCN_PLAN_KEEP_PERMUTATION) != 0;
+                if (keep_perm && (o.flags & H2GCN_PLAN_HOST_TRANSPOSE))
+                    return fail(H2GCN_ERR_INVALID_ARGUMENT, "H2GCN_PLAN_KEEP_PERMUTATION needs the device transposition");
                 std::vector<int64_t> t_rowptr(n_cols + 1);
                 std::string terr;
                 int st = (o.flags & H2GCN_PLAN_HOST_TRANSPOSE)
                              ? -1
                              : h2gcn::transpose_csr_device(n_rows, n_cols, nnz, rowptr_dev[k], colidx_dev[k], vals_dev[k],
-                                                           &t_rp, &t_ci, &t_va, stream, &terr);
+                                                           &t_rp, &t_ci, &t_va, keep_perm ? &t_perm : nullptr, stream, &terr);
+                if (st != 0 && keep_perm && st != -3)
+                    return fail(H2GCN_ERR_INVALID_ARGUMENT, "H2GCN_PLAN_KEEP_PERMUTATION: %s", terr.c_str());
                 if (st == 0) {
                     plan->owned.emplace_back(); plan->owned.back().p = t_rp;
                     plan->owned.emplace_back(); plan->owned.back().p = t_ci;
                     plan->owned.emplace_back(); plan->owned.back().p = t_va;
+                    plan->owned.emplace_back(); plan->owned.back().p = t_perm;
                     H2GCN_HIP_TRY(hipMemcpy(t_rowptr.data(), t_rp, (n_cols + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
                 } else if (st == -3) {
                     return fail(H2GCN_ERR_OUT_OF_MEMORY, "transposition of hop %d: %s", k, terr.c_str());
@@ -447,6 +456,7 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
                 op.colidx = t_ci;
                 op.vals = t_va;
                 op.nnz = nnz;
+                op.perm = t_perm;
                 collect_long_rows(t_rowptr, n_cols, plan->long_threshold, op.long_rows);
             }
             plan->has_transpose = true;
@@ -471,6 +481,24 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
 }
 
 void h2gcn_plan_destroy(h2gcn_plan_t* plan) { delete plan; }
+
+int h2gcn_plan_set_values(h2gcn_plan_t* plan, int hop, const float* vals_dev, void* stream_v) {
+    if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (hop < 0 || hop >= plan->n_hops) return fail(H2GCN_ERR_INVALID_ARGUMENT, "hop %d outside 0..%d", hop, plan->n_hops - 1);
+    HopOperand& f = plan->fwd[hop];
+    if (f.nnz > 0 && !vals_dev) return fail(H2GCN_ERR_INVALID_ARGUMENT, "vals is NULL");
+    int st = check_device(plan);
+    if (st != H2GCN_OK) return st;
+    if (plan->has_transpose) {
+        HopOperand& a = plan->adj[hop];
+        if (a.nnz > 0 && !a.perm)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan has transposed operands but was created without H2GCN_PLAN_KEEP_PERMUTATION");
+        h2gcn::permute_values(a.perm, vals_dev, a.nnz, const_cast<float*>(a.vals), (hipStream_t)stream_v);
+        H2GCN_HIP_TRY(hipGetLastError());
+    }
+    f.vals = vals_dev;
+    return H2GCN_OK;
+}
 
 int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t* n_cols, int64_t* nnz,
                     int64_t* n_long_segments, int32_t* has_transpose) {
@@ -525,13 +553,23 @@ size_t h2gcn_spmm_workspace_bytes(const h2gcn_plan_t* plan, uint32_t hop_mask, i
 
 int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X, int64_t ldx, int32_t d,
                         float* Y, int64_t ldy_row, int64_t ldy_hop, void* stream_v) {
-    return h2gcn_spmm_hops_ws_f32(plan, hop_mask, X, ldx, d, Y, ldy_row, ldy_hop, nullptr, 0, stream_v);
+    return h2gcn_spmm_hops_opts_f32(plan, hop_mask, X, ldx, d, Y, ldy_row, ldy_hop, nullptr, stream_v);
 }
 
-int h2gcn_spmm_hops_ws_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X, int64_t ldx, int32_t d,
-                           float* Y, int64_t ldy_row, int64_t ldy_hop, void* workspace, size_t workspace_bytes,
-                           void* stream_v) {
+int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X, int64_t ldx, int32_t d,
+                             float* Y, int64_t ldy_row, int64_t ldy_hop, const h2gcn_launch_opts* lopts,
+                             void* stream_v) {
     try {
+        h2gcn_launch_opts lo;
+        memset(&lo, 0, sizeof(lo));
+        if (lopts) {
+            if (lopts->struct_size < 8 || lopts->struct_size > sizeof(lo))
+                return fail(H2GCN_ERR_INVALID_ARGUMENT, "launch opts struct_size = %u", lopts->struct_size);
+            memcpy(&lo, lopts, lopts->struct_size);
+        }
+        if (lo.flags & ~(uint32_t)H2GCN_LAUNCH_RELU) return fail(H2GCN_ERR_INVALID_ARGUMENT, "unknown launch flags 0x%x", lo.flags);
+        void* workspace = lo.workspace_dev;
+        const size_t workspace_bytes = lo.workspace_bytes;
         if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
         uint32_t mask;
         int st = resolve_mask(plan, hop_mask, &mask);
@@ -566,6 +604,8 @@ int h2gcn_spmm_hops_ws_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const fl
         p.ld_src = ldx;
         p.dst = Y;
         p.ld_dst = ldy_row;
+        p.bias = lo.bias_dev;
+        p.relu = (lo.flags & H2GCN_LAUNCH_RELU) ? 1 : 0;
         st = get_long_list(plan, false, mask, &p.long_list, &p.n_long);
         if (st != H2GCN_OK) return st;
         p.long_threshold = plan->long_threshold;
@@ -594,7 +634,7 @@ int h2gcn_spmm_hops_ws_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const fl
         return launch<false>(p, plan->variant, vec_ok, off32, forced_slice, plan->n_cols,
                              (double)nnz_sel / ((double)p.n_rows * s), (hipStream_t)stream_v);
     } catch (...) {
-        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_f32");
+        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_opts_f32");
     }
 }
 

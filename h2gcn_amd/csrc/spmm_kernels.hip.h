@@ -74,6 +74,8 @@ struct LaunchParams {
     int n_slices;          // column slices of slice_cols features, processed slice-major (EXACT kernels)
     int slice_cols;
     int64_t blocks_per_slice;  // n_long + 8 * tiles_per_xcd
+    const float* bias;         // optional epilogue: dst = act(sum + bias[col]); NULL = none
+    int relu;                  // optional epilogue: act = max(., 0)
 };
 
 template <int VEC>
@@ -292,6 +294,20 @@ __device__ __forceinline__ void accumulate_segment_prefetched(const int32_t* __r
     }
 }
 
+// Optional fused epilogue of the store (reference SparseDense.call, h2gcn/models/_layers.py:45-52: `+ bias`, then the
+// activation): applied to the finished sum of an output element, columns col .. col+VEC-1.
+template <int VEC>
+__device__ __forceinline__ void epilogue(float (&acc)[VEC], const float* __restrict__ bias, int relu, int col) {
+    if (bias) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += bias[col + i];
+    }
+    if (relu) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaxf(acc[i], 0.f);
+    }
+}
+
 template <int VEC>
 __device__ __forceinline__ void store_vec(float* p, const float (&acc)[VEC]) {
     if constexpr (VEC == 1) {
@@ -370,6 +386,8 @@ __global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hop
                 float t = partial[0][c];
 #pragma unroll
                 for (int w = 1; w < kWavesPerBlock; ++w) t += partial[w][c];
+                if (p.bias) t += p.bias[col0 + c];
+                if (p.relu) t = fmaxf(t, 0.f);
                 const int64_t off = row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_first]) + col0 + c;
                 __builtin_nontemporal_store(t, p.dst + off);
             }
@@ -442,8 +460,10 @@ __global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hop
                 if (!skipped) {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
-                    if (g == 0 && store_ok)
+                    if (g == 0 && store_ok) {
+                        epilogue<VEC>(acc, p.bias, p.relu, col_begin + li * VEC);
                         store_vec<VEC>(p.dst + row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_cur]) + col_begin + li * VEC, acc);
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
@@ -478,8 +498,10 @@ __global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hop
                 if constexpr (!SUM) {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
-                    if (g == 0 && lane_active && store_ok)
+                    if (g == 0 && lane_active && store_ok) {
+                        epilogue<VEC>(acc, p.bias, p.relu, col0 + li * VEC);
                         store_vec<VEC>(p.dst + row * p.ld_dst + p.dst_hop_off[s] + col0 + li * VEC, acc);
+                    }
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
                 }
@@ -487,7 +509,10 @@ __global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hop
             if constexpr (SUM) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
-                if (g == 0 && lane_active && store_ok) store_vec<VEC>(p.dst + row * p.ld_dst + col0 + li * VEC, acc);
+                if (g == 0 && lane_active && store_ok) {
+                    epilogue<VEC>(acc, p.bias, p.relu, col0 + li * VEC);
+                    store_vec<VEC>(p.dst + row * p.ld_dst + col0 + li * VEC, acc);
+                }
             }
         }
     }

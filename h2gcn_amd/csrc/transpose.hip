@@ -79,7 +79,8 @@ struct Scratch {
 // arrays are fresh hipMalloc allocations owned by the caller (t_colidx / t_vals are NULL when nnz == 0).
 int transpose_csr_device(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                          const float* vals, int64_t** t_rowptr_out, int32_t** t_colidx_out, float** t_vals_out,
-                         hipStream_t stream, std::string* err) {
+                         uint32_t** perm_out_keep, hipStream_t stream, std::string* err) {
+    if (perm_out_keep) *perm_out_keep = nullptr;
     *t_rowptr_out = nullptr;
     *t_colidx_out = nullptr;
     *t_vals_out = nullptr;
@@ -116,7 +117,24 @@ int transpose_csr_device(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
     *t_rowptr_out = (int64_t*)d_rowptr.p; d_rowptr.p = nullptr;
     *t_colidx_out = (int32_t*)d_col.p; d_col.p = nullptr;
     *t_vals_out = (float*)d_val.p; d_val.p = nullptr;
+    if (perm_out_keep) {  // transposed entry i came from forward entry perm[i]: lets the caller refresh the values later
+        *perm_out_keep = (uint32_t*)perm_out.p;
+        perm_out.p = nullptr;
+    }
     return 0;
+}
+
+// t_vals[i] = vals[perm[i]]: new values for an already transposed operand (same sparsity pattern)
+__global__ void permute_values_kernel(const uint32_t* __restrict__ perm, const float* __restrict__ vals, int64_t nnz,
+                                      float* __restrict__ t_vals) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
+        t_vals[i] = vals[perm[i]];
+}
+
+void permute_values(const uint32_t* perm, const float* vals, int64_t nnz, float* t_vals, hipStream_t stream) {
+    if (nnz <= 0) return;
+    const int64_t b = (nnz + 255) / 256;
+    hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)(b > 65536 ? 65536 : b)), dim3(256), 0, stream, perm, vals, nnz, t_vals);
 }
 
 }  // namespace h2gcn

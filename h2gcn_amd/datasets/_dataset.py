@@ -137,7 +137,7 @@ class PlanetoidData:
         density = f.nnz / max(1, f.shape[0] * f.shape[1])
         if density >= self.DENSE_FEATURE_THRESHOLD:
             return torch.from_numpy(np.asarray(f.todense(), dtype=np.float32)).to(device)
-        return HopPlan.from_scipy([f], device, build_transpose=build_transpose)
+        return HopPlan.from_scipy([f], device, build_transpose=build_transpose, keep_permutation=True)  # SparseDropout
 
     def get_tensors(self, device, adj_norm_hops: Optional[Sequence[str]] = None, norm: str = operands.SYM_NORMALIZED,
                     build_transpose: bool = True, host_hops: bool = False, shard=None) -> dict:

@@ -37,7 +37,8 @@ class HopPlan:
     def __init__(self, rowptr: Sequence[torch.Tensor], colidx: Sequence[torch.Tensor],
                  vals: Sequence[torch.Tensor], n_cols: int, *, build_transpose: bool = False,
                  long_row_threshold: int = 0, rows_per_wave: int = 0, variant: int = 0,
-                 slice_cols: int = 0, validate: bool = True, host_transpose: bool = False):
+                 slice_cols: int = 0, validate: bool = True, host_transpose: bool = False,
+                 keep_permutation: bool = False):
         H = len(rowptr)
         _require(1 <= H <= _capi.MAX_HOPS, f"need 1..{_capi.MAX_HOPS} hop matrices, got {H}")
         _require(len(colidx) == H and len(vals) == H, "rowptr/colidx/vals lists differ in length")
@@ -74,7 +75,8 @@ class HopPlan:
         opts = _capi.PlanOpts()
         opts.struct_size = C.sizeof(_capi.PlanOpts)
         opts.flags = ((_capi.PLAN_BUILD_TRANSPOSE if build_transpose else 0) | (0 if validate else _capi.PLAN_SKIP_VALIDATION)
-                      | (_capi.PLAN_HOST_TRANSPOSE if host_transpose else 0))
+                      | (_capi.PLAN_HOST_TRANSPOSE if host_transpose else 0)
+                      | (_capi.PLAN_KEEP_PERMUTATION if keep_permutation and build_transpose else 0))
         opts.long_row_threshold = int(long_row_threshold)
         opts.rows_per_wave = int(rows_per_wave)
         opts.variant = int(variant)
@@ -107,6 +109,16 @@ class HopPlan:
             vals.append(torch.from_numpy(m.data.astype(np.float32)).to(device))
         _require(n_cols is not None, "empty hop list")
         return cls(rowptr, colidx, vals, n_cols, **kw)
+
+    def set_values(self, hop: int, vals: torch.Tensor) -> None:
+        """New values for hop ``hop`` (same pattern); the transposed operand is refreshed too (plans built with
+        ``keep_permutation=True``).  ``vals`` is borrowed like the original arrays.  See ``h2gcn_plan_set_values``."""
+        _require(vals.dtype == torch.float32 and vals.device == self.device and vals.is_contiguous()
+                 and vals.numel() == self.colidx[hop].numel(), "vals must be a contiguous float32 array of the hop's nnz")
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _capi.check(_capi.lib().h2gcn_plan_set_values(self._handle, int(hop), C.c_void_p(vals.data_ptr()), C.c_void_p(stream)))
+        self.vals[hop] = vals
 
     # ------------------------------------------------------------------ introspection
     @property
@@ -146,8 +158,10 @@ class HopPlan:
         return self.n_hops if hops is None else bin(self._mask(hops)).count("1")
 
     # ------------------------------------------------------------------ launches
-    def spmm(self, x: torch.Tensor, hops=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """``out[i, s, :] = sum_j A_s[i, j] * x[j, :]`` for the selected hops -> ``[n_rows, H_sel, d]``.
+    def spmm(self, x: torch.Tensor, hops=None, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+             relu: bool = False) -> torch.Tensor:
+        """``out[i, s, :] = act(sum_j A_s[i, j] * x[j, :] + bias)`` for the selected hops -> ``[n_rows, H_sel, d]``
+        (``bias`` [d] and ``relu`` are the optional fused epilogue of the store; default: the plain sum).
 
         ``out`` may be any fp32 tensor view of shape ``[n_rows, H_sel, d]`` whose last dim is contiguous
         (e.g. a column slice of a wider concat buffer)."""
@@ -176,10 +190,17 @@ class HopPlan:
             # (0 bytes otherwise); a torch allocation, so it is stream-ordered and capturable in a hipGraph
             ws_bytes = int(L.h2gcn_spmm_workspace_bytes(self._handle, mask, x.stride(0), d)) if self.use_workspace else 0
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device) if ws_bytes else None
-            st = L.h2gcn_spmm_hops_ws_f32(self._handle, mask, C.c_void_p(x.data_ptr()), x.stride(0), d,
-                                          C.c_void_p(out.data_ptr()), out.stride(0), out.stride(1) if h_sel > 1 else d,
-                                          C.c_void_p(ws.data_ptr() if ws is not None else None), ws_bytes,
-                                          C.c_void_p(stream))
+            opts = None
+            if ws is not None or bias is not None or relu:
+                if bias is not None:
+                    _require(bias.dtype == torch.float32 and bias.device == self.device and bias.numel() == d and bias.is_contiguous(),
+                             f"bias must be a contiguous float32 [{d}] tensor on the plan's device")
+                opts = _capi.LaunchOpts(struct_size=C.sizeof(_capi.LaunchOpts), flags=_capi.LAUNCH_RELU if relu else 0,
+                                        workspace=ws.data_ptr() if ws is not None else None, workspace_bytes=ws_bytes,
+                                        bias=bias.data_ptr() if bias is not None else None)
+            st = L.h2gcn_spmm_hops_opts_f32(self._handle, mask, C.c_void_p(x.data_ptr()), x.stride(0), d,
+                                            C.c_void_p(out.data_ptr()), out.stride(0), out.stride(1) if h_sel > 1 else d,
+                                            C.byref(opts) if opts is not None else None, C.c_void_p(stream))
         _capi.check(st)
         return out
 

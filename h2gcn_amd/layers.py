@@ -70,6 +70,58 @@ class GCNLayer(torch.nn.Module):
         return f"hops={None if self.hops is None else sorted(self.hops)}"
 
 
+class SparseDropout(torch.nn.Module):
+    """Dropout on the VALUES of the sparse feature operand (reference ``SparseDropout``, ``_layers.py:7-19``: mask =
+    ``floor(keep_prob + U[0,1))`` per stored value, survivors divided by ``keep_prob``; reached when ``D`` precedes the
+    first dense layer, ``H2GCN.py:250-257``).  The operand is a 1-hop :class:`HopPlan`; its pattern is static, so the
+    layer writes the masked values into one persistent buffer (dropped entries as explicit zeros -- the same product as
+    ``tf.sparse.retain``) and points the plan at it (``HopPlan.set_values``, which also refreshes the transposed
+    operand the kernel gradient needs).  In eval mode the original values are put back."""
+
+    def __init__(self, drop_prob: float):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+        self._buf = None
+
+    def forward(self, plan: HopPlan) -> HopPlan:
+        if not isinstance(plan, HopPlan) or plan.n_hops != 1:
+            raise TypeError("SparseDropout expects the sparse feature operand as a 1-hop HopPlan")
+        orig = getattr(plan, "_values_before_dropout", None)
+        if not self.training or self.drop_prob <= 0.0:
+            if orig is not None and plan.vals[0] is not orig:
+                plan.set_values(0, orig)
+            return plan
+        if orig is None:
+            orig = plan._values_before_dropout = plan.vals[0]
+        if self._buf is None or self._buf.shape != orig.shape or self._buf.device != orig.device:
+            self._buf = torch.empty_like(orig)
+        keep = 1.0 - self.drop_prob
+        mask = torch.floor(torch.rand_like(orig) + keep)
+        torch.mul(orig, mask / keep, out=self._buf)
+        plan.set_values(0, self._buf)
+        return plan
+
+
+class _SparseDenseFused(torch.autograd.Function):
+    """``act(X_sp @ W + b)`` in ONE launch: bias and ReLU are the store epilogue of the hop kernel (reference
+    ``SparseDense.call``, ``_layers.py:45-52``).  Backward: ``g = dY * (Y > 0)``; ``dW = X_sp^T g`` (adjoint launch),
+    ``db = sum_rows g``."""
+
+    @staticmethod
+    def forward(ctx, kernel, bias, plan, relu):
+        y = plan.spmm(kernel, bias=bias, relu=relu)[:, 0, :]
+        ctx.plan, ctx.relu, ctx.has_bias = plan, relu, bias is not None
+        ctx.save_for_backward(y if relu else torch.empty(0, device=y.device))
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        (y,) = ctx.saved_tensors
+        g = grad * (y > 0) if ctx.relu else grad
+        d_kernel = ctx.plan.spmm_t(g.contiguous().unsqueeze(1))
+        return d_kernel, (g.sum(0) if ctx.has_bias else None), None, None
+
+
 class SparseDense(torch.nn.Module):
     """Sparse features x dense kernel (reference ``SparseDense``, ``h2gcn/models/_layers.py:22-52``): the feature
     embedding ``X_sp[N, F] @ W[F, units]`` (+ bias, + activation).  The sparse operand is a 1-hop
@@ -88,11 +140,15 @@ class SparseDense(torch.nn.Module):
             raise TypeError("SparseDense expects the sparse feature operand as a 1-hop HopPlan")
         if inputs.n_cols != self.kernel.shape[0]:
             raise ValueError(f"features have {inputs.n_cols} columns, kernel has {self.kernel.shape[0]} rows")
+        relu = self.activation in ("relu", torch.relu, torch.nn.functional.relu) or isinstance(self.activation, torch.nn.ReLU)
+        if self.bias is not None or relu:   # bias / ReLU fused into the store of the sparse product
+            if inputs.has_transpose or not (self.kernel.requires_grad and torch.is_grad_enabled()):
+                return _SparseDenseFused.apply(self.kernel, self.bias, inputs, relu)
         out = hop_spmm(inputs, self.kernel)[:, 0, :]
         if self.bias is not None:
             out = out + self.bias
         if self.activation is not None:
-            out = self.activation(out)
+            out = torch.relu(out) if relu else self.activation(out)
         return out
 
 

@@ -360,7 +360,9 @@ class H2GCN(torch.nn.Module):
         width = int(input_dim)       # width of the running activation (per node)
         tag_width = {}
         pending_hops = None          # set after a G layer until the next V: activation is [N, H, width]
-        for kind, conf in layer_setups:
+        setups = list(layer_setups)
+        fuse_relu_into = None        # index of a SparseDense whose following R layer became its store epilogue
+        for pos, (kind, conf) in enumerate(setups):
             conf = dict(conf)
             tag = conf.pop("tag", None)
             ind = len(self.layer_objs)
@@ -370,16 +372,19 @@ class H2GCN(torch.nn.Module):
                 if conf.get("beginOutput"):
                     self.output_ind = ind
                 if sparse_input:
-                    layer = L.SparseDense(width, conf["units"], use_bias=conf["use_bias"])
+                    # `M64-R`: the ReLU becomes the store epilogue of the sparse product (one pass over the embedding
+                    # instead of two) unless the pre-activation itself is observable (tagged / embedding / supervised)
+                    nxt = setups[pos + 1][0] if pos + 1 < len(setups) else None
+                    fuse = nxt == Layer.RELU and tag is None and not conf.get("isEmbedding") and not conf.get("supervised")
+                    layer = L.SparseDense(width, conf["units"], use_bias=conf["use_bias"], activation="relu" if fuse else None)
+                    fuse_relu_into = ind if fuse else None
                     sparse_input = False
                 else:
                     layer = Dense(width, conf["units"], conf["use_bias"])
                 self.regularized.append(layer)
                 width = conf["units"]
             elif kind == Layer.DROPOUT:
-                if sparse_input:
-                    raise NotImplementedError("dropout on the sparse input (SparseDropout) is not supported")
-                layer = torch.nn.Dropout(conf["dropout_rate"])
+                layer = L.SparseDropout(conf["dropout_rate"]) if sparse_input else torch.nn.Dropout(conf["dropout_rate"])
             elif kind == Layer.SLICE:
                 self.concat_inds.add(ind)
                 layer = L.SliceLayer(**conf)
@@ -396,7 +401,7 @@ class H2GCN(torch.nn.Module):
                 sel = n_hops if conf["hops"] is None else len([h for h in range(n_hops) if h in conf["hops"]])
                 pending_hops = sel
             elif kind == Layer.RELU:
-                layer = torch.nn.ReLU()
+                layer = torch.nn.Identity() if fuse_relu_into == ind - 1 else torch.nn.ReLU()
             elif kind == Layer.VECTORIZE:
                 layer = torch.nn.Flatten(start_dim=1)
                 if pending_hops is not None:
@@ -460,11 +465,14 @@ class H2GCN(torch.nn.Module):
                 return inputs
             if ind < execute_after:
                 continue
-            if fuse and self.fused is not None and ind == self.fused[0] and not (ind < return_before < self.fused[1]) \
-                    and adjhops.n_rows == adjhops.n_cols:
-                # concat-free propagation: layers fused[0] .. fused[1]-1 in one go
+            if fuse and self.fused is not None and ind == self.fused[0] and not (ind < return_before < self.fused[1]):
+                # concat-free propagation: layers fused[0] .. fused[1]-1 in one go (row-sharded runs: the shard's
+                # rows of the same buffer, one exchange per round)
                 _, end, K, tags = self.fused
-                inputs = L.fused_propagation(adjhops, inputs, K)
+                if hasattr(adjhops, "fused_propagation"):
+                    inputs = adjhops.fused_propagation(inputs, K)
+                else:
+                    inputs = L.fused_propagation(adjhops, inputs, K)
                 skip_until = end
                 w0 = tagged[tags[0]].shape[1]
                 H = adjhops.n_hops

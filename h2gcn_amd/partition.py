@@ -269,33 +269,35 @@ class PipelinedHopAggregation:
             for c in range(self.C):
                 self._gather(self.full[c], self.send[c], self.group)
 
-    def _spmm(self, x, out):
+    def _spmm(self, x, out, hops=None):
         if self.kernel_events is None or not self.use_streams:
-            self.plan.spmm(x, out=out)
+            self.plan.spmm(x, hops=hops, out=out)
             return
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        self.plan.spmm(x, out=out)
+        self.plan.spmm(x, hops=hops, out=out)
         e.record()
         self.kernel_events.append((s, e))
 
-    def __call__(self, x_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def __call__(self, x_local: torch.Tensor, out: Optional[torch.Tensor] = None, hops=None) -> torch.Tensor:
+        """``x_local`` [n_local, d] (any row stride) -> ``out`` [n_local, H_sel, d] (any strides, last dim contiguous);
+        ``hops`` = the hop filter of ``GCNLayer(hops=...)`` (reference ``_layers.py:57-59,80-81``)."""
         n_local = self.r1 - self.r0
         if tuple(x_local.shape) != (n_local, self.d):
             raise ValueError(f"local embedding has shape {tuple(x_local.shape)}, expected {(n_local, self.d)}")
-        H = self.plan.n_hops
+        H = self.plan.n_selected(hops)
         if out is None:
             out = torch.empty((n_local, H, self.d), dtype=torch.float32, device=self.device)
         cols = [slice(o, o + w) for o, w in zip(self.offsets, self.widths)]
         if self.world == 1:
             for c in range(self.C):  # chunked on one GPU: same schedule without the exchange
-                self._spmm(x_local[:, cols[c]], out[:, :, cols[c]])
+                self._spmm(x_local[:, cols[c]], out[:, :, cols[c]], hops)
             return out
         if not self.use_streams:
             for c in range(self.C):
                 self.send[c][:n_local].copy_(x_local[:, cols[c]])
                 self._gather(self.full[c], self.send[c], self.group)
-                self._spmm(self.full[c][: self.n], out[:, :, cols[c]])
+                self._spmm(self.full[c][: self.n], out[:, :, cols[c]], hops)
             return out
         if self.ipc is not None:
             # staging + notification of every chunk first (device-side order matters, see exchange.hip), pulls run on
@@ -304,7 +306,7 @@ class PipelinedHopAggregation:
                 self.ipc.begin(c, x_local[:, cols[c]], self.full[c], self.per)
             for c in range(self.C):
                 self.ipc.end(c)
-                self._spmm(self.full[c][: self.n], out[:, :, cols[c]])
+                self._spmm(self.full[c][: self.n], out[:, :, cols[c]], hops)
             return out
         main = torch.cuda.current_stream(self.device)
         for c in range(self.C):  # stage chunk by chunk so that the first exchange can start after the first copy
@@ -317,7 +319,7 @@ class PipelinedHopAggregation:
                 self.ready[c].record(self.comm_stream)
         for c in range(self.C):
             main.wait_event(self.ready[c])
-            self._spmm(self.full[c][: self.n], out[:, :, cols[c]])
+            self._spmm(self.full[c][: self.n], out[:, :, cols[c]], hops)
         return out
 
 
@@ -361,6 +363,16 @@ def _reduce_scatter_rows(full: torch.Tensor, per: int, rank: int, group=None) ->
     return out
 
 
+def _reduce_scatter_dx(layer: "PipelinedHopAggregation", dx_full: torch.Tensor) -> torch.Tensor:
+    """Full-height adjoint contribution ``A_k[rows_p, :]^T dY_p`` ([N, d]) -> this rank's rows of the summed gradient."""
+    if layer.world == 1:
+        return dx_full
+    padded = torch.zeros((layer.world * layer.per, dx_full.shape[1]), dtype=dx_full.dtype, device=dx_full.device)
+    padded[: layer.n] = dx_full
+    mine = _reduce_scatter_rows(padded, layer.per, layer.rank, layer.group)
+    return mine[: layer.r1 - layer.r0]
+
+
 class _ShardedHopSpMM(torch.autograd.Function):
     """Row-sharded GCNLayer with autograd: forward = all-gather(X) + local fused SpMM (pipelined); backward = the
     adjoint on the local shard, which yields a full-height contribution ``A_k[rows_p, :]^T dY_p``, summed across
@@ -368,27 +380,63 @@ class _ShardedHopSpMM(torch.autograd.Function):
     SURVEY.md §8e)."""
 
     @staticmethod
-    def forward(ctx, x_local, layer):
-        ctx.layer = layer
-        return layer(x_local)
+    def forward(ctx, x_local, layer, hops):
+        ctx.layer, ctx.hops = layer, hops
+        return layer(x_local, hops=hops)
 
     @staticmethod
     def backward(ctx, grad_y):
         layer = ctx.layer
-        dx_full = layer.plan.spmm_t(grad_y.contiguous())  # [N, d]
-        if layer.world == 1:
-            return dx_full, None
-        padded = torch.zeros((layer.world * layer.per, layer.d), dtype=dx_full.dtype, device=dx_full.device)
-        padded[: layer.n] = dx_full
-        mine = _reduce_scatter_rows(padded, layer.per, layer.rank, layer.group)
-        return mine[: layer.r1 - layer.r0], None
+        dx_full = layer.plan.spmm_t(grad_y.contiguous(), hops=ctx.hops)  # [N, d]
+        return _reduce_scatter_dx(layer, dx_full), None, None
 
 
-def sharded_hop_spmm(layer: "PipelinedHopAggregation", x_local: torch.Tensor) -> torch.Tensor:
-    """Differentiable row-sharded hop aggregation: ``[n_local, d] -> [n_local, H, d]``."""
+def sharded_hop_spmm(layer: "PipelinedHopAggregation", x_local: torch.Tensor, hops=None) -> torch.Tensor:
+    """Differentiable row-sharded hop aggregation: ``[n_local, d] -> [n_local, H_sel, d]``."""
     if x_local.requires_grad and torch.is_grad_enabled():
-        return _ShardedHopSpMM.apply(x_local, layer)
-    return layer(x_local)
+        return _ShardedHopSpMM.apply(x_local, layer, hops)
+    return layer(x_local, hops=hops)
+
+
+class _ShardedFusedPropagation(torch.autograd.Function):
+    """Row-sharded form of :class:`h2gcn_amd.layers._FusedPropagation`: the K aggregation rounds of H2GCN-K write
+    straight into this rank's ``[n_local, W]`` concat buffer ``[r_K | r_0 | ... | r_{K-1}]``.  Round k all-gathers the
+    slot holding ``r_{k-1}`` (read in place, row stride W) and lands ``r_k`` in its slot through the kernel's output
+    strides -- none of the stack / flatten / concat copies the layer-by-layer interpreter would make.  Backward walks
+    the rounds in reverse: shard adjoint, reduce-scatter, add the slot's incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, r0, hops_obj, rounds):
+        plan = hops_obj.plan
+        n_local, w0 = r0.shape
+        H = plan.n_hops
+        widths = [w0 * H ** k for k in range(rounds + 1)]
+        off = [0] * (rounds + 1)
+        pos = widths[rounds]
+        for k in range(rounds):
+            off[k] = pos
+            pos += widths[k]
+        buf = torch.empty((n_local, sum(widths)), dtype=torch.float32, device=r0.device)
+        buf[:, off[0]:off[0] + w0].copy_(r0)
+        for k in range(1, rounds + 1):
+            src = buf[:, off[k - 1]:off[k - 1] + widths[k - 1]]
+            dst = buf[:, off[k]:off[k] + widths[k]].unflatten(1, (H, widths[k - 1]))
+            hops_obj.pipeline(widths[k - 1])(src, out=dst)
+        ctx.hops_obj, ctx.rounds, ctx.widths, ctx.off = hops_obj, rounds, widths, off
+        return buf
+
+    @staticmethod
+    def backward(ctx, grad):
+        hops_obj, K, widths, off = ctx.hops_obj, ctx.rounds, ctx.widths, ctx.off
+        plan = hops_obj.plan
+        H = plan.n_hops
+        g_k = grad[:, off[K]:off[K] + widths[K]]
+        for k in range(K, 0, -1):
+            layer = hops_obj.pipeline(widths[k - 1])
+            g_prev = _reduce_scatter_dx(layer, plan.spmm_t(g_k.unflatten(1, (H, widths[k - 1]))))
+            g_prev = g_prev + grad[:, off[k - 1]:off[k - 1] + widths[k - 1]]
+            g_k = g_prev
+        return g_k, None, None
 
 
 class ShardedHops:
@@ -417,9 +465,26 @@ class ShardedHops:
         return self._pipes[d]
 
     def aggregate(self, x_local: torch.Tensor, hops=None) -> torch.Tensor:
+        """``GCNLayer(hops=...)`` on the shard: ``hops`` keeps the listed hop indices (unknown ones are ignored like the
+        reference's ``if ind in self.hops`` filter, ``_layers.py:80-81``)."""
+        sel = None
         if hops is not None:
-            raise NotImplementedError("hop filters (G0, G0_1, ...) are not supported in row-partitioned runs yet")
-        return sharded_hop_spmm(self.pipeline(int(x_local.shape[1])), x_local)
+            sel = tuple(h for h in range(self.n_hops) if h in set(int(v) for v in hops))
+            if not sel:
+                raise ValueError(f"GCNLayer(hops={sorted(hops)}) selects none of the {self.n_hops} hops")
+        return sharded_hop_spmm(self.pipeline(int(x_local.shape[1])), x_local, sel)
+
+    def fused_propagation(self, r0_local: torch.Tensor, rounds: int) -> torch.Tensor:
+        """``[r_K | r_0 | ... | r_{K-1}]`` of this rank's rows without intermediate copies (see
+        :class:`_ShardedFusedPropagation`)."""
+        if rounds < 1 or r0_local.dim() != 2 or r0_local.shape[0] != self.n_rows:
+            raise ValueError(f"r0 must be [{self.n_rows}, d] and rounds >= 1")
+        if r0_local.requires_grad and torch.is_grad_enabled():
+            return _ShardedFusedPropagation.apply(r0_local, self, rounds)
+
+        class _Ctx:
+            pass
+        return _ShardedFusedPropagation.forward(_Ctx(), r0_local, self, rounds)
 
 
 def slice_csr_rows(rowptr: torch.Tensor, colidx: torch.Tensor, vals: torch.Tensor, r0: int, r1: int):

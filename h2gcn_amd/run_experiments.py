@@ -1,4 +1,6 @@
-"""Entry point: ``python -m h2gcn_amd.run_experiments <model> <datafmt> [flags]``.
+"""Entry point: ``python run_experiments.py <model> <datafmt> [flags]`` from inside the package directory -- how the
+reference is launched (cwd ``h2gcn/``, ``experiments/h2gcn/experiments_workflow.py:301-318``) -- or, equivalently,
+``python -m h2gcn_amd.run_experiments <model> <datafmt> [flags]`` from anywhere.
 
 Same driver contract as the reference's ``h2gcn/run_experiments.py`` (``:7-12, 31-61``): positional ``model`` and
 ``datafmt`` plugins, ``--epochs`` (2000), ``--random_seed`` (123), plugin hooks fill ``args.objects`` with
@@ -9,6 +11,14 @@ the callbacks.  Example (planetoid files of Cora in ./data):
 """
 import os
 import time
+
+if __package__ in (None, ""):  # run as a script (`python run_experiments.py ...`): make the package importable
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    __package__ = "h2gcn_amd"
+    import h2gcn_amd  # noqa: F401
 
 import torch
 import torch.distributed as dist

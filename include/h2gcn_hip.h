@@ -58,6 +58,9 @@ typedef enum h2gcn_status {
 #define H2GCN_PLAN_HOST_TRANSPOSE  0x4u /* build A_k^T with the host counting sort instead of the device radix
                                            sort (debug / cross-check; same result)                            */
 
+#define H2GCN_PLAN_KEEP_PERMUTATION 0x8u /* with BUILD_TRANSPOSE: remember which forward entry every transposed entry
+                                           came from, so that h2gcn_plan_set_values can refresh A_k^T (+4 B/nonzero) */
+
 /* Tunables of the CSR-adaptive schedule.  Zero in a field means "library default". */
 typedef struct h2gcn_plan_opts {
     uint32_t struct_size;        /* = sizeof(h2gcn_plan_opts), for forward compatibility                   */
@@ -111,6 +114,16 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols,
 /* Release the plan and everything it owns (never the caller's CSR arrays).  NULL is a no-op. */
 void h2gcn_plan_destroy(h2gcn_plan_t* plan);
 
+/*
+ * Replace the VALUES of hop `hop` (same sparsity pattern: rowptr/colidx unchanged).  Stands in for what
+ * SparseDropout does to the sparse feature operand every training step (reference h2gcn/models/_layers.py:7-19:
+ * a fresh Bernoulli mask on `input.values`, survivors scaled by 1/keep_prob): the caller writes the new values
+ * (dropped entries as explicit zeros) and points the plan at them; transposed operands are refreshed on `stream`
+ * (needs H2GCN_PLAN_KEEP_PERMUTATION).  `vals_dev` must stay alive like the original array.  This MUTATES the plan:
+ * it must not run concurrently with launches of the same plan on other streams.
+ */
+int h2gcn_plan_set_values(h2gcn_plan_t* plan, int hop, const float* vals_dev, void* stream);
+
 /* Introspection (for reports and tests).  Any out pointer may be NULL. */
 int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t* n_cols, int64_t* nnz,
                     int64_t* n_long_segments, int32_t* has_transpose);
@@ -146,18 +159,31 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
                         int32_t d, float* Y_dev, int64_t ldy_row, int64_t ldy_hop, void* stream);
 
 /*
- * Same launch with caller-provided scratch.  When the row stride of X is a multiple of 1 KiB (e.g. a contiguous
- * [N, 256] embedding) and the operand is far beyond the caches, gathering column slices straight out of X wastes
- * three quarters of the cache sets; the launch then first copies X into a slice-major layout inside `workspace`
- * (one streaming pass, ~3 % of the launch) and gathers from there.  h2gcn_spmm_workspace_bytes() says how much
- * scratch such a launch wants (0 = the plain launch is already the fastest); a NULL / too small workspace simply
- * selects the plain launch.  Results are bit-identical either way.  The scratch is only used by this launch (on
- * `stream`); launches that may run concurrently need separate scratch.
+ * Same launch with options.
+ *
+ * workspace / workspace_bytes: caller-provided scratch.  When the row stride of X is a multiple of 1 KiB (e.g. a
+ *   contiguous [N, 256] embedding) and the operand is far beyond the caches, gathering column slices straight out
+ *   of X wastes three quarters of the cache sets; the launch then first copies X into a slice-major layout inside
+ *   the scratch (one streaming pass, ~3 % of the launch) and gathers from there.  h2gcn_spmm_workspace_bytes() says
+ *   how much scratch such a launch wants (0 = the plain launch is already the fastest); NULL / too small simply
+ *   selects the plain launch.  Results are bit-identical either way.  The scratch is only used by this launch (on
+ *   `stream`); launches that may run concurrently need separate scratch.
+ * bias / H2GCN_LAUNCH_RELU: fused epilogue of the store, Y = act(A X + bias[c]) -- what SparseDense.call applies
+ *   after its sparse product (reference h2gcn/models/_layers.py:45-52: `+ self.bias`, then `self.activation`), so
+ *   that the feature embedding needs no second pass over its output.  bias: d floats (device) or NULL.
  */
+#define H2GCN_LAUNCH_RELU 0x1u
+typedef struct h2gcn_launch_opts {
+    uint32_t struct_size;      /* = sizeof(h2gcn_launch_opts)                                               */
+    uint32_t flags;            /* H2GCN_LAUNCH_*                                                             */
+    void* workspace_dev;       /* scratch or NULL                                                            */
+    size_t workspace_bytes;
+    const float* bias_dev;     /* d floats or NULL                                                           */
+} h2gcn_launch_opts;
 size_t h2gcn_spmm_workspace_bytes(const h2gcn_plan_t* plan, uint32_t hop_mask, int64_t ldx, int32_t d);
-int h2gcn_spmm_hops_ws_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X_dev, int64_t ldx,
-                           int32_t d, float* Y_dev, int64_t ldy_row, int64_t ldy_hop, void* workspace_dev,
-                           size_t workspace_bytes, void* stream);
+int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X_dev, int64_t ldx,
+                             int32_t d, float* Y_dev, int64_t ldy_row, int64_t ldy_hop,
+                             const h2gcn_launch_opts* opts, void* stream);
 
 /*
  * Adjoint (backward wrt X):

@@ -186,3 +186,15 @@ def test_reader_of_the_generator_format_matches_reference_conversion(tmp_path):
     assert (masks == 1).all() and data.train_mask.sum() == 100 and data.val_mask.sum() == 100
     with __import__("pytest").raises(FileNotFoundError):
         read_generated_graph(tmp_path, "missing")
+
+
+def test_script_launch_from_the_package_directory():
+    """The reference is launched as `python run_experiments.py ...` with cwd = its package directory
+    (experiments/h2gcn/experiments_workflow.py:301-318); the same line works here."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    pkg = Path(__file__).resolve().parents[1] / "h2gcn_amd"
+    r = subprocess.run([sys.executable, "run_experiments.py", "H2GCN", "planetoid", "--help"], cwd=pkg, capture_output=True, text=True)
+    assert r.returncode == 0 and "--network_setup" in r.stdout and "--dataset_path" in r.stdout, r.stderr[-2000:]

@@ -285,3 +285,17 @@ def test_zero_epochs_reports_the_untrained_model(tmp_path, capsys):
     _cora_files(tmp_path)
     args = run_experiments.main(["H2GCN", "planetoid", "--dataset", "ind.cora", "--dataset_path", str(tmp_path), "--epochs", "0"])
     assert args.objects["best_val_stats"]["epoch"] == 0 and "Best performance:" in capsys.readouterr().out
+
+
+def test_sparse_dropout_network_trains(tmp_path, capsys):
+    """`D` before the first dense layer = SparseDropout on the feature operand (reference H2GCN.py:250-257)."""
+    from h2gcn_amd import run_experiments
+    from h2gcn_amd.layers import SparseDropout
+
+    _cora_files(tmp_path)
+    args = run_experiments.main(["H2GCN", "planetoid", "--dataset", "ind.cora", "--dataset_path", str(tmp_path), "--epochs", "40",
+                                 "--random_seed", "5", "--network_setup", "D0.3-M64-R-T1-G-V-T2-G-V-C1-C2-D0.5-MO"])
+    model = args.objects["model"]
+    assert isinstance(model.layer_objs[0], SparseDropout)
+    best = args.objects["best_val_stats"]
+    assert best["val_acc"] >= 0.6 and args.objects["epoch_stats"]["train_loss"] < 1.9

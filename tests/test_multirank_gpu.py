@@ -92,14 +92,16 @@ import json, os, sys
 sys.path.insert(0, os.environ["H2GCN_ROOT"])
 from h2gcn_amd import run_experiments
 args = run_experiments.main(["H2GCN", "planetoid", "--dataset", "ind.cora", "--dataset_path", os.environ["DATA_DIR"],
-                             "--epochs", "6", "--random_seed", "11", "--network_setup", "M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO"])
+                             "--epochs", "6", "--random_seed", "11", "--network_setup", os.environ["NETWORK"]])
 if int(os.environ.get("RANK", "0")) == 0:
     stats = {k: float(v) for k, v in args.objects["epoch_stats"].items() if k != "monitor"}
     json.dump(stats, open(os.environ["OUT_FILE"], "w"))
 '''
 
 
-def test_row_partitioned_training_matches_single_process(tmp_path):
+@pytest.mark.parametrize("network", ["M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO",          # H2GCN-2: concat-free sharded propagation
+                                     "M64-R-T1-G0-V-T2-G0_1-V-C1_2-D0.0-MO"])     # hop filters on the shards
+def test_row_partitioned_training_matches_single_process(tmp_path, network):
     """`run_experiments` under torch.distributed (2 ranks, rows of features / hop matrices / labels partitioned,
     dense kernels replicated, all-gather forward, reduce-scatter + gradient all-reduce backward) follows the
     single-process training trajectory.  Dropout is disabled so both runs are deterministic."""
@@ -115,7 +117,7 @@ def test_row_partitioned_training_matches_single_process(tmp_path):
         procs = []
         out_file = tmp_path / f"stats{world}.json"
         for rank in range(world):
-            env = dict(os.environ, H2GCN_ROOT=str(ROOT), DATA_DIR=str(data_dir), OUT_FILE=str(out_file))
+            env = dict(os.environ, H2GCN_ROOT=str(ROOT), DATA_DIR=str(data_dir), OUT_FILE=str(out_file), NETWORK=network)
             if world > 1:
                 env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                            MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1")

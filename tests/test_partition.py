@@ -69,12 +69,19 @@ def _worker(rank, world, port, n, d, out_dir):
             n_rows, n_cols, n_hops = r1 - r0, n, 2
 
             @staticmethod
-            def spmm(x, out):
-                out.copy_(torch.from_numpy(og.gcn_layer_c(shard, x.contiguous().numpy())))
+            def n_selected(hops):
+                return 2 if hops is None else len(hops)
 
             @staticmethod
-            def spmm_t(grad):
-                return torch.from_numpy(og.gcn_layer_grad_c(shard, grad.numpy(), n))
+            def spmm(x, hops=None, out=None):
+                sel = shard if hops is None else [shard[h] for h in hops]
+                y = torch.from_numpy(og.gcn_layer_c(sel, x.contiguous().numpy()))
+                return y if out is None else out.copy_(y)
+
+            @staticmethod
+            def spmm_t(grad, hops=None):
+                sel = shard if hops is None else [shard[h] for h in hops]
+                return torch.from_numpy(og.gcn_layer_grad_c(sel, grad.contiguous().numpy(), n))
 
         for chunks in (1, 2, 4, [4, 4, 8]):
             for exchange in ("allgather", "p2p"):
@@ -83,8 +90,28 @@ def _worker(rank, world, port, n, d, out_dir):
                 assert y_pipe.shape == (r1 - r0, 2, d)
                 assert np.array_equal(y_pipe.numpy(), y_local), (chunks, exchange)
 
+        # hop filters (GCNLayer(hops=...), reference _layers.py:57-59,80-81) and the concat-free propagation on shards
+        from h2gcn_amd.partition import ShardedHops, sharded_hop_spmm
+
+        sh = ShardedHops(OraclePlan, n, "cpu", chunk_cols=4)
+        assert np.array_equal(sh.aggregate(x_local, hops=[1]).numpy(), y_local[:, 1:2])
+        assert np.array_equal(sh.aggregate(x_local, hops={0, 1, 5}).numpy(), y_local)
+        xa = x_local.clone().requires_grad_(True)
+        (sh.aggregate(xa, hops=[0]) * 2.0).sum().backward()
+        np.save(Path(out_dir) / f"dx_hop0_{rank}.npy", xa.grad.numpy())
+        xf = x_local.clone().requires_grad_(True)
+        buf = sh.fused_propagation(xf, 2)                                  # [r2 | r0 | r1] of this rank's rows
+        xg = x_local.clone().requires_grad_(True)
+        r1_ = sh.aggregate(xg).flatten(1)
+        r2_ = sh.aggregate(r1_).flatten(1)
+        ref = torch.cat([r2_, xg, r1_], 1)
+        assert buf.shape == (r1 - r0, 7 * d) and torch.equal(buf, ref)
+        wt = torch.from_numpy(synth.synth_features_np(7 * d, 21, r0, r1))
+        (buf * wt).sum().backward()
+        (ref * wt).sum().backward()
+        assert (xf.grad - xg.grad).abs().max().item() <= 1e-5
+
         # distributed backward: adjoint on the shard + reduce-scatter == rows [r0, r1) of the global adjoint
-        from h2gcn_amd.partition import sharded_hop_spmm
 
         w_full = synth.synth_features_np(2 * d, 9, 0, n).reshape(n, 2, d)
         xl = x_local.clone().requires_grad_(True)
@@ -97,6 +124,7 @@ def _worker(rank, world, port, n, d, out_dir):
                 rp, ci, va = synth.synth_hop_rows_np(degs[k], n, s, 0, n)
                 full_ops.append(sp.csr_matrix((va, ci, rp), shape=(n, n)))
             np.save(Path(out_dir) / "dx_full.npy", og.gcn_layer_grad_c(full_ops, w_full, n))
+            np.save(Path(out_dir) / "dx_hop0_full.npy", og.gcn_layer_grad_c(full_ops[:1], np.full((n, 1, d), 2.0, dtype=np.float32), n))
         if rank == 0:  # single-process answer on the unpartitioned operands
             full = []
             for k, s in enumerate((1, 2)):
@@ -120,3 +148,5 @@ def test_row_partition_allgather_equals_single_rank(world, n, tmp_path):
     dx = np.concatenate([np.load(tmp_path / f"dx{r}.npy") for r in range(world)], 0)
     want = np.load(tmp_path / "dx_full.npy")
     assert dx.shape == want.shape and np.abs(dx - want).max() <= 1e-5  # sum over ranks re-associates the adjoint
+    dx0 = np.concatenate([np.load(tmp_path / f"dx_hop0_{r}.npy") for r in range(world)], 0)
+    assert np.abs(dx0 - np.load(tmp_path / "dx_hop0_full.npy")).max() <= 1e-5   # hop-filtered backward

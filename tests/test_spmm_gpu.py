@@ -181,8 +181,9 @@ def test_slice_major_scratch_copy_is_bitwise_identical():
     # a workspace that is too small silently selects the plain launch
     small = torch.empty(1024, dtype=torch.uint8, device=device)
     y3 = torch.empty_like(y_ws)
-    _capi.check(L.h2gcn_spmm_hops_ws_f32(plan._handle, 0, C.c_void_p(x.data_ptr()), d, d, C.c_void_p(y3.data_ptr()), 2 * d, d,
-                                         C.c_void_p(small.data_ptr()), 1024, None))
+    opts = _capi.LaunchOpts(struct_size=C.sizeof(_capi.LaunchOpts), flags=0, workspace=small.data_ptr(), workspace_bytes=1024, bias=None)
+    _capi.check(L.h2gcn_spmm_hops_opts_f32(plan._handle, 0, C.c_void_p(x.data_ptr()), d, d, C.c_void_p(y3.data_ptr()), 2 * d, d,
+                                           C.byref(opts), None))
     torch.cuda.synchronize()
     assert torch.equal(y3, y_plain)
     for r0 in (0, 12345, n - 8):
@@ -192,6 +193,98 @@ def test_slice_major_scratch_copy_is_bitwise_identical():
         remap = {c: i for i, c in enumerate(cols)}
         local = [(q[0], np.array([remap[c] for c in q[1]], dtype=np.int32), q[2]) for q in parts]
         assert np.abs(y_ws[r0:r0 + 8].cpu().numpy() - og.rows_subset(local, xs, list(range(8)))).max() <= ATOL
+
+
+@pytest.mark.parametrize("d", [64, 100, 7])
+def test_fused_bias_relu_epilogue(d):
+    """Y = relu(A X + b) in one launch (SparseDense.call: bias, then activation, reference _layers.py:45-52): every
+    store path (regular, pipelined, long segment, generic scalar) against the oracle + numpy epilogue, bitwise equal
+    to the unfused launch followed by torch ops."""
+    from h2gcn_amd import HopPlan
+
+    n = 600
+    hops = [rand_csr(n, n, 0.02, 3, empty_frac=0.15)]
+    hops[0] = sp.csr_matrix(sp.vstack([hops[0][:7], sp.csr_matrix(np.full((1, n), 0.02, dtype=np.float32)), hops[0][8:]]))
+    rng = np.random.default_rng(d)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, d).astype(np.float32)
+    want = og.gcn_layer_f64acc(hops, x)
+    xt, bt = torch.from_numpy(x).to(dev()), torch.from_numpy(b).to(dev())
+    for variant in (0, 2):
+        plan = HopPlan.from_scipy(hops, dev(), variant=variant, long_row_threshold=128)
+        plain = plan.spmm(xt)
+        for bias, relu in ((bt, True), (bt, False), (None, True)):
+            y = plan.spmm(xt, bias=bias, relu=relu)
+            ref = plain + bias if bias is not None else plain
+            ref = torch.relu(ref) if relu else ref
+            assert torch.equal(y, ref), (variant, bias is not None, relu)
+            w = want + (b if bias is not None else 0)
+            w = np.maximum(w, 0) if relu else w
+            assert np.abs(y.cpu().numpy() - w).max() <= ATOL
+    with pytest.raises(ValueError):
+        plan.spmm(xt, bias=bt[:-1])
+
+
+def test_sparse_dense_fused_gradients():
+    """SparseDense with the fused bias/ReLU epilogue: outputs and gradients equal the unfused composition."""
+    from h2gcn_amd import HopPlan
+    from h2gcn_amd.layers import SparseDense
+
+    feats = rand_csr(500, 300, 0.03, 5, empty_frac=0.05)
+    plan = HopPlan.from_scipy([feats], dev(), build_transpose=True)
+    torch.manual_seed(0)
+    fused = SparseDense(300, 64, use_bias=True, activation="relu").to(dev())
+    plain = SparseDense(300, 64, use_bias=True, activation=None).to(dev())
+    plain.load_state_dict(fused.state_dict())
+    with torch.no_grad():
+        fused.bias.uniform_(-0.1, 0.1)
+        plain.bias.copy_(fused.bias)
+    w = torch.rand((500, 64), device=dev())
+    yf = fused(plan)
+    yp = torch.relu(plain(plan) if False else (plan.spmm(plain.kernel)[:, 0, :] + plain.bias))
+    assert torch.equal(yf, yp)
+    (yf * w).sum().backward()
+    k = plain.kernel.detach().clone().requires_grad_(True)
+    bb = plain.bias.detach().clone().requires_grad_(True)
+    dense = torch.from_numpy(feats.toarray()).to(dev())
+    (torch.relu(dense @ k + bb) * w).sum().backward()
+    assert (fused.kernel.grad - k.grad).abs().max().item() <= 1e-4
+    assert (fused.bias.grad - bb.grad).abs().max().item() <= 1e-4
+
+
+def test_set_values_refreshes_forward_and_adjoint_and_sparse_dropout():
+    """h2gcn_plan_set_values (SparseDropout's effect on the feature operand, reference _layers.py:7-19): new values on
+    the same pattern, forward AND transposed operand follow; the SparseDropout layer masks ~drop_prob of the stored
+    values, rescales the survivors, and restores the original values in eval mode."""
+    from h2gcn_amd import HopPlan
+    from h2gcn_amd._capi import H2GCNError
+    from h2gcn_amd.layers import SparseDropout
+
+    feats = rand_csr(800, 500, 0.02, 9)
+    plan = HopPlan.from_scipy([feats], dev(), build_transpose=True, keep_permutation=True)
+    x = torch.rand((500, 32), device=dev())
+    g = torch.rand((800, 1, 32), device=dev())
+    rng = np.random.default_rng(0)
+    new = feats.copy()
+    new.data = rng.uniform(-1, 1, new.nnz).astype(np.float32)
+    orig_vals = plan.vals[0]
+    plan.set_values(0, torch.from_numpy(new.data).to(dev()))
+    assert np.abs(plan.spmm(x).cpu().numpy() - og.gcn_layer_f64acc([new], x.cpu().numpy())).max() <= ATOL
+    assert np.abs(plan.spmm_t(g).cpu().numpy() - og.gcn_layer_grad_c([new], g.cpu().numpy(), 500)).max() <= 2e-5
+    plan.set_values(0, orig_vals)
+    assert np.abs(plan.spmm_t(g).cpu().numpy() - og.gcn_layer_grad_c([feats], g.cpu().numpy(), 500)).max() <= 2e-5
+    no_perm = HopPlan.from_scipy([feats], dev(), build_transpose=True)
+    with pytest.raises(H2GCNError):
+        no_perm.set_values(0, orig_vals)
+    drop = SparseDropout(0.4).train()
+    torch.manual_seed(1)
+    out = drop(plan)
+    v = out.vals[0]
+    kept = (v != 0)
+    assert 0.5 < kept.float().mean().item() < 0.7
+    assert torch.allclose(v[kept], orig_vals[kept] / 0.6)
+    assert torch.equal(drop.eval()(plan).vals[0], orig_vals)                      # eval: original operand again
+    assert np.abs(plan.spmm(x).cpu().numpy() - og.gcn_layer_f64acc([feats], x.cpu().numpy())).max() <= ATOL
 
 
 @pytest.mark.parametrize("n_rows,n_cols", [(1, 1), (5, 9), (63, 64), (64, 63), (65, 1000), (1000, 17), (4097, 333)])
