@@ -224,7 +224,7 @@ int repack_slice_cols(const h2gcn_plan* plan, int64_t nnz_sel, int n_sel, int64_
 }
 
 struct Schedule {
-    bool pipe, scalar128, exact;
+    bool pipe, scalar128, exact, shortrow;
     int slice;
 };
 
@@ -240,7 +240,11 @@ Schedule decide(int variant, bool vec_ok, int d, int rows_per_wave, int n_sel, i
     const bool sliced_ok = vec_ok && d % 4 == 0;        // float4 lanes; a partial last slice is masked
     sc.slice = (sliced_ok && !sc.scalar128) ? pick_slice_cols(d, n_src_rows, forced_slice, avg_segment_nnz) : 0;
     sc.exact = sc.slice > 0 || sc.scalar128;
-    sc.pipe = sc.pipe && sc.exact;
+    // short segments: one lane group per segment (G segments of a wave in flight at once) -- slices of 64 / 128 columns;
+    // variant 5 forces it, variants 2 / 3 keep the wave-per-segment walk with / without the index prefetch
+    sc.shortrow = (variant == 5 || (variant == 0 && avg_segment_nnz < 16.0)) && sc.exact && !sc.scalar128 &&
+                  (sc.slice == 64 || sc.slice == 128);
+    sc.pipe = sc.pipe && sc.exact && !sc.shortrow;
     return sc;
 }
 
@@ -249,7 +253,8 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
            double avg_segment_nnz, hipStream_t stream) {
     using namespace h2gcn;
     const Schedule sc = decide(variant, vec_ok, p.d, p.rows_per_wave, p.n_sel, forced_slice, n_src_rows, avg_segment_nnz);
-    const bool pipe = sc.pipe, scalar128 = sc.scalar128, exact = sc.exact;
+    const bool epi = !SUM && (p.bias != nullptr || p.relu != 0);  // bias / ReLU epilogue: dedicated instantiations
+    const bool pipe = sc.pipe && !epi, scalar128 = sc.scalar128, exact = sc.exact, shortrow = sc.shortrow && !epi;
     const int slice = sc.slice;
     p.slice_cols = exact ? (slice > 0 ? slice : 128) : p.d;
     p.n_slices = exact ? (p.d + p.slice_cols - 1) / p.slice_cols : 1;
@@ -259,9 +264,20 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
     if (n_blocks <= 0) return H2GCN_OK;
     if (n_blocks > 0x7fffffffLL) return fail(H2GCN_ERR_INVALID_ARGUMENT, "grid too large (%lld blocks)", (long long)n_blocks);
     const dim3 grid((unsigned)n_blocks), block(kBlock);
+#define H2GCN_LAUNCH_SHORT(VEC, LPR)                                                                                    \
+    do {                                                                                                                \
+        if (off32)                                                                                                      \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, true, false, true>), grid, block, 0, stream, p);   \
+        else                                                                                                            \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, false, false, true>), grid, block, 0, stream, p);  \
+    } while (0)
 #define H2GCN_LAUNCH(VEC, LPR, EXACT)                                                                             \
     do {                                                                                                          \
-        if (off32 && pipe && EXACT)                                                                               \
+        if (epi && off32)                                                                                         \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, true, false, false, !SUM>), grid, block, 0, stream, p);  \
+        else if (epi)                                                                                             \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, false, false, false, !SUM>), grid, block, 0, stream, p); \
+        else if (off32 && pipe && EXACT)                                                                               \
             hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, true, true>), grid, block, 0, stream, p);   \
         else if (off32)                                                                                           \
             hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, true, false>), grid, block, 0, stream, p);  \
@@ -274,6 +290,10 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
         H2GCN_LAUNCH(2, 64, true);  // one neighbour per load instruction, scalar base addressing
     } else if (slice == 256) {
         H2GCN_LAUNCH(4, 64, true);
+    } else if (slice == 128 && shortrow) {
+        H2GCN_LAUNCH_SHORT(4, 32);
+    } else if (slice == 64 && shortrow) {
+        H2GCN_LAUNCH_SHORT(4, 16);
     } else if (slice == 128) {
         H2GCN_LAUNCH(4, 32, true);
     } else if (slice == 64) {
@@ -286,6 +306,7 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
         H2GCN_LAUNCH(1, 64, false);  // d % 4 != 0 or unaligned operands: scalar column-tiled path
     }
 #undef H2GCN_LAUNCH
+#undef H2GCN_LAUNCH_SHORT
     H2GCN_HIP_TRY(hipGetLastError());
     return H2GCN_OK;
 }
@@ -533,7 +554,7 @@ int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint
     const int w = sc.exact ? (sc.slice > 0 ? sc.slice : 128) : d;
     if (slice_cols) *slice_cols = w;
     if (n_slices) *n_slices = sc.exact ? (d + w - 1) / w : 1;
-    if (index_prefetch) *index_prefetch = sc.pipe ? 1 : 0;
+    if (index_prefetch) *index_prefetch = sc.pipe ? 1 : (sc.shortrow ? 2 : 0);
     if (scratch_copy) *scratch_copy = rs > 0 ? 1 : 0;
     return H2GCN_OK;
 }

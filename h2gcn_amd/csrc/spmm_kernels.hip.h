@@ -294,6 +294,54 @@ __device__ __forceinline__ void accumulate_segment_prefetched(const int32_t* __r
     }
 }
 
+// ---- short-row mode ("one lane group per segment") ------------------------------------------------------------
+// When segments are short (a handful of nonzeros: 1-hop matrices of citation-like graphs, mean degree 4-8), giving
+// a whole wave to one segment leaves the kernel latency-bound: one segment = one dependent chain index -> gather ->
+// fold -> store with a single 1 KiB load in flight.  Here the G lane groups of a wave take G DIFFERENT segments
+// (same hop, G consecutive rows) and walk them in lock step: G segments' gathers are in flight together and no
+// cross-lane fold is needed.  The arithmetic is arranged to be BIT-IDENTICAL to the wave-per-segment mode: that mode
+// sums neighbour j into the partial of lane group j % G and then folds the partials in a fixed tree; a group here
+// keeps the same G partials in registers and combines them in the same tree -- so which mode served a row can never
+// be seen in the result (row partitions, rows_per_wave and tile geometry stay invisible).
+// Handles segments of at most LPR nonzeros (one index fetch per group): `c`, `v` hold the group's indices/values
+// lane-wise (lane li of the group = neighbour li), `n_mine` its length, `n_max` the longest of the round (uniform).
+template <int VEC, int LPR, bool OFF32>
+__device__ __forceinline__ void accumulate_grouped(int c, float v, int n_mine, int n_max, int lane,
+                                                   const GatherAddr<OFF32>& addr, float (&part)[kWave / LPR][VEC]) {
+    constexpr int G = kWave / LPR;
+    constexpr int U = G < 4 ? 4 : G;  // neighbours per batch (a multiple of G so that j % G is a compile-time constant)
+    const int group_base = lane & ~(LPR - 1);
+    for (int t = 0; t < n_max; t += U) {
+        typename VecT<VEC>::type x[U];
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cj = lane_gather(c, group_base + t + u);
+            w[u] = lane_gather(v, group_base + t + u);
+            if (t + u < n_mine) {
+                x[u] = load_vec<VEC>(addr.row(cj));
+            } else {
+                w[u] = 0.f;
+                if constexpr (VEC == 1) x[u] = 0.f; else x[u] = (typename VecT<VEC>::type)(0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (t + u < n_mine) fma_vec<VEC>(part[u % G], w[u], x[u]);
+    }
+}
+
+// the fixed tree of fold_groups<LPR>, applied to partials held in registers: G = 2: p0 + p1; G = 4: (p0+p1) + (p2+p3)
+template <int VEC, int G>
+__device__ __forceinline__ void combine_partials(const float (&part)[G][VEC], float (&acc)[VEC]) {
+    static_assert(G == 2 || G == 4, "short-row mode supports 2 or 4 lane groups");
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        if constexpr (G == 2) acc[i] = part[0][i] + part[1][i];
+        else acc[i] = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+    }
+}
+
 // Optional fused epilogue of the store (reference SparseDense.call, h2gcn/models/_layers.py:45-52: `+ bias`, then the
 // activation): applied to the finished sum of an output element, columns col .. col+VEC-1.
 template <int VEC>
@@ -330,8 +378,12 @@ __device__ __forceinline__ void store_vec(float* p, const float (&acc)[VEC]) {
 //        not store.  Otherwise (!EXACT) LPR == 64 and each wave loops over masked column tiles (any d, any alignment)
 // SUM    adjoint mode: one output row = sum over the selected hops
 // OFF32  32-bit gather offsets (see GatherAddr)
-template <int VEC, int LPR, bool EXACT, bool SUM, bool OFF32, bool PIPE = false>
-__global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hops_kernel(const LaunchParams p) {
+// SHORT  short-row mode (see accumulate_grouped): rounds of G segments whose lengths are all <= LPR are served one
+//        lane group per segment; other rounds fall back to the wave-per-segment walk.  Same bits either way.
+// EPI    the store applies the optional bias / ReLU epilogue (separate instantiations: the epilogue's registers would
+//        otherwise push the 6-waves-per-SIMD variants of the plain aggregation into spilling)
+template <int VEC, int LPR, bool EXACT, bool SUM, bool OFF32, bool PIPE = false, bool SHORT = false, bool EPI = false>
+__global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? 4 : kMinWavesPerSimd) : 2) void spmm_hops_kernel(const LaunchParams p) {
     static_assert(EXACT || LPR == kWave, "column-tiled path uses the whole wave per row");
     __shared__ float partial[kWavesPerBlock][kMaxTileCols];
     using off_t = typename std::conditional<OFF32, uint32_t, int64_t>::type;
@@ -386,8 +438,10 @@ __global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hop
                 float t = partial[0][c];
 #pragma unroll
                 for (int w = 1; w < kWavesPerBlock; ++w) t += partial[w][c];
-                if (p.bias) t += p.bias[col0 + c];
-                if (p.relu) t = fmaxf(t, 0.f);
+                if constexpr (EPI) {
+                    if (p.bias) t += p.bias[col0 + c];
+                    if (p.relu) t = fmaxf(t, 0.f);
+                }
                 const int64_t off = row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_first]) + col0 + c;
                 __builtin_nontemporal_store(t, p.dst + off);
             }
@@ -416,6 +470,171 @@ __global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hop
     auto seg_bound = [&](int l) -> int64_t {
         return ((int64_t)__builtin_amdgcn_readlane(rp_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(rp_lo, l);
     };
+
+    if constexpr (SHORT && EXACT && (kWave / LPR == 2 || kWave / LPR == 4)) {
+        constexpr int G = kWave / LPR;
+        const int group_lane0 = lane & ~(LPR - 1);
+        const int short_max = min(LPR, p.long_threshold - 1);
+        const int n_blocks = (rows_here + G - 1) / G;       // row blocks of G consecutive rows
+        const GatherAddr<OFF32> addr0{nullptr, (off_t)(li_src * VEC * 4), (off_t)(p.ld_src * 4)};
+        // wave-per-segment walk of one row (all hops in SUM mode, hop `s_only` otherwise) -- the general path
+        auto row_wave_wide = [&](int r, int s_first, int s_last) {
+            float acc[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            if constexpr (SUM) {
+                for (int s = s_first; s < s_last; ++s) {
+                    const int l0 = s * (rpw + 1) + r;
+                    if (seg_bound(l0 + 1) - seg_bound(l0) >= p.long_threshold) return;  // row owned by the long path
+                }
+            }
+            for (int s = s_first; s < s_last; ++s) {
+                const int l0 = s * (rpw + 1) + r;
+                const int64_t sb = seg_bound(l0), se = seg_bound(l0 + 1);
+                if (!SUM && se - sb >= p.long_threshold) continue;
+                const HopCsr& h = p.hop[s];
+                GatherAddr<OFF32> addr = addr0;
+                addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin);
+                accumulate_segment<VEC, LPR, false, OFF32>(h.colidx, h.vals, sb, se, 0, 1, addr, lane, true, acc);
+                if constexpr (!SUM) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
+                    if (g == 0 && store_ok) {
+                        if constexpr (EPI) epilogue<VEC>(acc, p.bias, p.relu, col_begin + li * VEC);
+                        store_vec<VEC>(p.dst + (row0 + r) * p.ld_dst + p.dst_hop_off[s] + col_begin + li * VEC, acc);
+                    }
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+                }
+            }
+            if constexpr (SUM) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
+                if (g == 0 && store_ok) store_vec<VEC>(p.dst + (row0 + r) * p.ld_dst + col_begin + li * VEC, acc);
+            }
+        };
+        // (begin, length) of the segment (hop s, row b*G + g) for this lane's group; length -1 for rows beyond the tile
+        auto my_segment = [&](int s, int blk, int64_t& begin, int& len) {
+            const int r = blk * G + g;
+            const int l0 = s * (rpw + 1) + min(r, rpw - 1);
+            const int64_t sb = ((int64_t)lane_gather(rp_hi, l0) << 32) | (uint32_t)lane_gather(rp_lo, l0);
+            const int64_t se = ((int64_t)lane_gather(rp_hi, l0 + 1) << 32) | (uint32_t)lane_gather(rp_lo, l0 + 1);
+            begin = sb;
+            const int64_t n = se - sb;
+            len = r < rows_here ? (int)(n > 0x7fffffff ? 0x7fffffff : n) : -1;
+        };
+        if constexpr (!SUM) {
+            // rounds (hop s, row block blk) in order; the index fetch of round i+1 is issued before round i gathers
+            // (loads retire in order, so it has landed by the time round i's gathers have) -- one memory latency per
+            // round instead of two
+            const int n_rounds = n_sel * n_blocks;
+            int64_t begin_n = 0;
+            int len_n = -1, c_n = 0;
+            float v_n = 0.f;
+            bool short_n = false;
+            auto fetch = [&](int i) {
+                const int s_ = i / n_blocks, blk_ = i - s_ * n_blocks;
+                my_segment(s_, blk_, begin_n, len_n);
+                short_n = __builtin_amdgcn_ballot_w64(len_n > short_max) == 0;
+                c_n = 0;
+                v_n = 0.f;
+                if (short_n && li < len_n) {
+                    c_n = __builtin_nontemporal_load(p.hop[s_].colidx + begin_n + li);
+                    v_n = __builtin_nontemporal_load(p.hop[s_].vals + begin_n + li);
+                }
+            };
+            if (n_rounds > 0) fetch(0);
+            for (int i = 0; i < n_rounds; ++i) {
+                const int s = i / n_blocks, blk = i - s * n_blocks;
+                const int len = len_n, c = c_n;
+                const float v = v_n;
+                const bool is_short = short_n;
+                if (i + 1 < n_rounds) fetch(i + 1);
+                if (is_short) {
+                    int n_max = 0;
+#pragma unroll
+                    for (int gg = 0; gg < G; ++gg) n_max = max(n_max, __builtin_amdgcn_readlane(len, gg * LPR));
+                    float part[G][VEC];
+#pragma unroll
+                    for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+                        for (int i2 = 0; i2 < VEC; ++i2) part[gg][i2] = 0.f;
+                    GatherAddr<OFF32> addr = addr0;
+                    addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin);
+                    accumulate_grouped<VEC, LPR, OFF32>(c, v, len, n_max, lane, addr, part);
+                    float acc[VEC];
+                    combine_partials<VEC, G>(part, acc);
+                    if (len >= 0 && store_ok) {
+                        if constexpr (EPI) epilogue<VEC>(acc, p.bias, p.relu, col_begin + li * VEC);
+                        store_vec<VEC>(p.dst + (row0 + blk * G + g) * p.ld_dst + p.dst_hop_off[s] + col_begin + li * VEC, acc);
+                    }
+                } else {
+                    for (int gg = 0; gg < G && blk * G + gg < rows_here; ++gg) row_wave_wide(blk * G + gg, s, s + 1);
+                }
+            }
+        } else {
+            // SUM mode: a row block is served group-per-row only if the segments of ALL selected hops are short; the
+            // partials run on across the hops exactly as the wave-per-segment walk's accumulators do.  Index fetches
+            // are issued one segment ahead (see the forward case).
+            auto block_short = [&](int blk_) {
+                bool ok = true;
+                for (int s_ = 0; s_ < n_sel; ++s_) {
+                    int64_t b_;
+                    int l_;
+                    my_segment(s_, blk_, b_, l_);
+                    ok = ok && __builtin_amdgcn_ballot_w64(l_ > short_max) == 0;
+                }
+                return ok;
+            };
+            int64_t begin_n = 0;
+            int len_n = -1, c_n = 0;
+            float v_n = 0.f;
+            auto fetch = [&](int blk_, int s_, bool short_blk) {
+                my_segment(s_, blk_, begin_n, len_n);
+                c_n = 0;
+                v_n = 0.f;
+                if (short_blk && li < len_n) {
+                    c_n = __builtin_nontemporal_load(p.hop[s_].colidx + begin_n + li);
+                    v_n = __builtin_nontemporal_load(p.hop[s_].vals + begin_n + li);
+                }
+            };
+            bool cur_short = n_blocks > 0 && block_short(0);
+            if (n_blocks > 0) fetch(0, 0, cur_short);
+            for (int blk = 0; blk < n_blocks; ++blk) {
+                const bool nxt_short = blk + 1 < n_blocks && block_short(blk + 1);
+                if (cur_short) {
+                    float part[G][VEC];
+#pragma unroll
+                    for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) part[gg][i] = 0.f;
+                    bool valid = false;
+                    for (int s = 0; s < n_sel; ++s) {
+                        const int len = len_n, c = c_n;
+                        const float v = v_n;
+                        valid = len >= 0;
+                        if (s + 1 < n_sel) fetch(blk, s + 1, true);
+                        else if (blk + 1 < n_blocks) fetch(blk + 1, 0, nxt_short);
+                        int n_max = 0;
+#pragma unroll
+                        for (int gg = 0; gg < G; ++gg) n_max = max(n_max, __builtin_amdgcn_readlane(len, gg * LPR));
+                        GatherAddr<OFF32> addr = addr0;
+                        addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin);
+                        accumulate_grouped<VEC, LPR, OFF32>(c, v, len, n_max, lane, addr, part);
+                    }
+                    float acc[VEC];
+                    combine_partials<VEC, G>(part, acc);
+                    if (valid && store_ok) store_vec<VEC>(p.dst + (row0 + blk * G + g) * p.ld_dst + col_begin + li * VEC, acc);
+                } else {
+                    if (blk + 1 < n_blocks) fetch(blk + 1, 0, nxt_short);
+                    for (int gg = 0; gg < G && blk * G + gg < rows_here; ++gg) row_wave_wide(blk * G + gg, 0, n_sel);
+                }
+                cur_short = nxt_short;
+            }
+        }
+        (void)group_lane0;
+        return;
+    }
 
     if constexpr (PIPE && EXACT) {
         // ---- software-pipelined walk over the wave's (row, hop) segments: prefetch the next segment's first
@@ -461,7 +680,7 @@ __global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hop
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
                     if (g == 0 && store_ok) {
-                        epilogue<VEC>(acc, p.bias, p.relu, col_begin + li * VEC);
+                        if constexpr (EPI) epilogue<VEC>(acc, p.bias, p.relu, col_begin + li * VEC);
                         store_vec<VEC>(p.dst + row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_cur]) + col_begin + li * VEC, acc);
                     }
                 }
@@ -499,7 +718,7 @@ __global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hop
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
                     if (g == 0 && lane_active && store_ok) {
-                        epilogue<VEC>(acc, p.bias, p.relu, col0 + li * VEC);
+                        if constexpr (EPI) epilogue<VEC>(acc, p.bias, p.relu, col0 + li * VEC);
                         store_vec<VEC>(p.dst + row * p.ld_dst + p.dst_hop_off[s] + col0 + li * VEC, acc);
                     }
 #pragma unroll
@@ -510,7 +729,7 @@ __global__ __launch_bounds__(kBlock, EXACT ? kMinWavesPerSimd : 2) void spmm_hop
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
                 if (g == 0 && lane_active && store_ok) {
-                    epilogue<VEC>(acc, p.bias, p.relu, col0 + li * VEC);
+                    if constexpr (EPI) epilogue<VEC>(acc, p.bias, p.relu, col0 + li * VEC);
                     store_vec<VEC>(p.dst + row * p.ld_dst + col0 + li * VEC, acc);
                 }
             }

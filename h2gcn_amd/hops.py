@@ -141,7 +141,8 @@ class HopPlan:
         ld = int(ld_src) if ld_src is not None else (self.n_selected(hops) * d if adjoint else d)
         _capi.check(L.h2gcn_plan_schedule(self._handle, self._mask(hops), 1 if adjoint else 0, ld, int(d),
                                           C.byref(sc), C.byref(ns), C.byref(pf), C.byref(cp)))
-        return dict(slice_cols=sc.value, n_slices=ns.value, index_prefetch=bool(pf.value),
+        return dict(slice_cols=sc.value, n_slices=ns.value, index_prefetch=pf.value == 1,
+                    segment_walk={0: "wave per segment", 1: "wave per segment + index prefetch", 2: "lane group per segment (short rows)"}[pf.value],
                     scratch_copy=bool(cp.value) and self.use_workspace)
 
     def _mask(self, hops) -> int:

@@ -71,7 +71,9 @@ typedef struct h2gcn_plan_opts {
     int32_t variant;             /* kernel variant: 0 = default (index prefetch across segments when segments
                                     average < 16 nonzeros); 1 = scalar-addressed float2 gathers at d=128;
                                     2 = always prefetch; 3 = never prefetch; 4 = default, but never use the
-                                    slice-major scratch copy (A/B measurements)                               */
+                                    slice-major scratch copy (A/B measurements); 5 = force the short-row mode
+                                    (one lane group per segment; default when segments average < 16 nonzeros
+                                    and the slice is 64 or 128 columns).  All variants give identical bits.    */
     int32_t slice_cols;          /* feature columns per slice of the slice-major schedule: 16/32/64/128/256,
                                     0 = heuristic (narrower slices when X is far beyond the Infinity Cache)  */
     int32_t reserved[2];
@@ -129,8 +131,8 @@ int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t*
                     int64_t* n_long_segments, int32_t* has_transpose);
 
 /* The schedule a launch of this plan would use for feature width d and source row stride ld_src (reports, tests):
- * columns per slice of the slice-major schedule, number of slices, whether the index prefetch across segments is
- * on, whether a forward launch with scratch would gather from a slice-major copy.  adjoint != 0 asks about
+ * columns per slice of the slice-major schedule, number of slices, segment walk (0 = wave per
+ * segment, 1 = the same with index prefetch across segments, 2 = short-row mode: one lane group per segment), whether a forward launch with scratch would gather from a slice-major copy.  adjoint != 0 asks about
  * h2gcn_spmm_hops_T_f32 (ld_src = ldg_row).  Any out pointer may be NULL. */
 int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, int64_t ld_src, int32_t d,
                         int32_t* slice_cols, int32_t* n_slices, int32_t* index_prefetch, int32_t* scratch_copy);

@@ -372,6 +372,43 @@ def test_variant_pipelined_segment_walk_is_bitwise_identical(d):
     assert_close(ref.spmm(x).cpu().numpy(), hops, x.cpu().numpy())
 
 
+@pytest.mark.parametrize("d", [64, 128, 256, 100])
+@pytest.mark.parametrize("mean_deg", [1.5, 6, 14])
+def test_short_row_mode_is_bitwise_identical(d, mean_deg):
+    """variant=5: rounds of G short segments are served one lane group per segment (G segments of a wave in flight at
+    once).  Each group keeps the G partial sums the wave-per-segment walk would have spread over its lane groups and
+    combines them in the same tree, so the bits are those of variant 3 -- forward, adjoint, hop selection, every
+    rows_per_wave, long rows and empty rows in the mix, thresholds below the group width."""
+    from h2gcn_amd import HopPlan
+
+    rng = np.random.default_rng(int(d * 10 + mean_deg))
+    n = 3000
+    hops = []
+    for k in range(2):
+        deg = np.minimum(rng.poisson(mean_deg * (k + 1), n), n)
+        deg[rng.random(n) < 0.1] = 0
+        deg[rng.integers(0, n, 3)] = [40, 200, 17]
+        rows = np.repeat(np.arange(n), deg)
+        cols = np.concatenate([rng.choice(n, kk, replace=False) for kk in deg])
+        m = sp.csr_matrix((rng.uniform(-1, 1, len(rows)).astype(np.float32), (rows, cols)), shape=(n, n))
+        m.sort_indices()
+        hops.append(m)
+    x = torch.from_numpy(rng.uniform(-1, 1, (n, d)).astype(np.float32)).to(dev())
+    w = torch.from_numpy(rng.uniform(-1, 1, (n, 2, d)).astype(np.float32)).to(dev())
+    for thr in (0, 8, 20):
+        ref = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr, variant=3)
+        for rpw in (0, 1, 3, 7):
+            for sc in (0, 64, 128):
+                alt = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr, variant=5, rows_per_wave=rpw, slice_cols=sc)
+                base = ref if sc == 0 else HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr, variant=3, slice_cols=sc)
+                assert torch.equal(base.spmm(x), alt.spmm(x)), (thr, rpw, sc)
+                assert torch.equal(base.spmm_t(w), alt.spmm_t(w)), (thr, rpw, sc)
+                assert torch.equal(base.spmm(x, hops=[1]), alt.spmm(x, hops=[1]))
+                assert torch.equal(base.spmm_t(w[:, :1].contiguous(), hops=[0]), alt.spmm_t(w[:, :1].contiguous(), hops=[0]))
+    assert_close(ref.spmm(x).cpu().numpy(), hops, x.cpu().numpy())
+    assert alt.schedule(d)["index_prefetch"] in (True, False)
+
+
 def test_variant_scalar_addressing_matches():
     hops = [rand_csr(500, 500, 0.1, 1), rand_csr(500, 500, 0.2, 2)]
     x = np.random.default_rng(1).uniform(-1, 1, (500, 128)).astype(np.float32)
