@@ -39,7 +39,10 @@ using h2gcn::fail;
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int64_t kLdsBitmapCols = 1 << 20;  // level 0 in LDS up to this many columns (128 KiB of the CU's 160 KiB)
+constexpr int64_t kLdsBitmapCols = 1 << 17;  // level 0 in LDS up to this many columns (16 KiB: 8 workgroups per CU);
+                                             // beyond that rows are sparse relative to n and occupancy matters more
+                                             // than LDS atomics: level 0 moves to L2-resident global slabs
+constexpr int kSlabsPerCu = 8;
 constexpr int kMaxPatterns = 8;
 
 struct Pattern {
@@ -85,6 +88,19 @@ __device__ __forceinline__ void unmark(uint32_t* l0, int32_t c) {
     }
 }
 
+// Level-0 words in global slabs are written with L2 atomics; read / reset them at agent scope as well so that no stale
+// line of this CU's vector L1 is ever consulted.
+template <bool L0_LDS>
+__device__ __forceinline__ uint32_t l0_read(const uint32_t* l0, int64_t w) {
+    if constexpr (L0_LDS) return l0[w];
+    else return __hip_atomic_load(l0 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool L0_LDS>
+__device__ __forceinline__ void l0_clear(uint32_t* l0, int64_t w) {
+    if constexpr (L0_LDS) l0[w] = 0;
+    else __hip_atomic_store(l0 + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // FILL == false: counts[i]; FILL == true: out_colidx[out_rowptr[i] ...] in ascending order.
 template <bool L0_LDS, bool FILL>
 __global__ __launch_bounds__(kThreads) void ring_kernel(const RingParams p) {
@@ -92,16 +108,16 @@ __global__ __launch_bounds__(kThreads) void ring_kernel(const RingParams p) {
     uint32_t* l1 = lds;                                   // [l1_words]
     uint32_t* l0 = L0_LDS ? lds + p.l1_words : p.l0_scratch + (int64_t)blockIdx.x * p.l0_words;
     __shared__ unsigned int row_s;
-    __shared__ uint32_t scan_s[kThreads];
+    __shared__ uint32_t wave_tot[kWaves];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // the bitmaps start zeroed (LDS part here, the global slabs by the host) and are left zeroed by every row
     for (int64_t w = tid; w < p.l1_words + (L0_LDS ? p.l0_words : 0); w += kThreads) lds[w] = 0;
     __syncthreads();
 
+    if (tid == 0) row_s = atomicAdd(p.ticket, 1u);
+    __syncthreads();
     while (true) {
-        if (tid == 0) row_s = atomicAdd(p.ticket, 1u);
-        __syncthreads();
         const int64_t i = row_s;
         if (i >= p.n) break;
 
@@ -137,20 +153,27 @@ __global__ __launch_bounds__(kThreads) void ring_kernel(const RingParams p) {
             while (m) {
                 const int b = __builtin_ctz(m);
                 m &= m - 1;
-                mine += __builtin_popcount(l0[w1 * 32 + b]);
+                mine += __builtin_popcount(l0_read<L0_LDS>(l0, w1 * 32 + b));
             }
         }
-        // block-wide exclusive prefix sum of `mine` (ascending thread id = ascending column)
-        scan_s[tid] = mine;
-        __syncthreads();
-        for (int off = 1; off < kThreads; off <<= 1) {
-            const uint32_t v = tid >= off ? scan_s[tid - off] : 0;
-            __syncthreads();
-            scan_s[tid] += v;
-            __syncthreads();
+        // block-wide exclusive prefix sum of `mine` (ascending thread id = ascending column): wave scan + 4 wave totals
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
         }
-        const uint32_t before = scan_s[tid] - mine;
-        if (!FILL && tid == kThreads - 1) p.counts[i] = scan_s[tid];
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const uint32_t t = wave_tot[w];
+            if (w < wave) base += t;
+            total += t;
+        }
+        const uint32_t before = base + incl - mine;
+        if (!FILL && tid == 0) p.counts[i] = total;
         int64_t pos = FILL ? p.out_rowptr[i] + before : 0;
         for (int64_t w1 = w1b; w1 < w1e; ++w1) {
             uint32_t m = l1[w1];
@@ -160,8 +183,8 @@ __global__ __launch_bounds__(kThreads) void ring_kernel(const RingParams p) {
                 const int b = __builtin_ctz(m);
                 m &= m - 1;
                 const int64_t w0 = w1 * 32 + b;
-                uint32_t bits = l0[w0];
-                l0[w0] = 0;
+                uint32_t bits = l0_read<L0_LDS>(l0, w0);
+                l0_clear<L0_LDS>(l0, w0);
                 if constexpr (FILL) {
                     while (bits) {
                         const int c = __builtin_ctz(bits);
@@ -171,7 +194,8 @@ __global__ __launch_bounds__(kThreads) void ring_kernel(const RingParams p) {
                 }
             }
         }
-        __syncthreads();  // bitmaps are zero again; row_s may be overwritten
+        if (tid == 0) row_s = atomicAdd(p.ticket, 1u);  // next row (every thread has read row_s and wave_tot by now:
+        __syncthreads();                                // the scan's barrier lies behind); bitmaps are zero again
     }
 }
 
@@ -216,7 +240,7 @@ size_t h2gcn_ring_scratch_bytes(int64_t n) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int64_t l0_words = (n + 31) / 32;
-    const size_t slabs = n > kLdsBitmapCols ? (size_t)cus * 2 * (size_t)l0_words * 4 : 0;
+    const size_t slabs = n > kLdsBitmapCols ? (size_t)cus * kSlabsPerCu * (size_t)l0_words * 4 : 0;
     return 64 + slabs;
 }
 
@@ -267,10 +291,10 @@ static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_
     const bool l0_lds = n <= kLdsBitmapCols;
     const size_t lds_bytes = (size_t)(p.l1_words + (l0_lds ? p.l0_words : 0)) * 4;
     // workgroups per CU the LDS footprint allows (160 KiB per CU, keep some for the static arrays), at most 8
-    int per_cu = l0_lds ? (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (lds_bytes + 2048))) : 2;
+    int per_cu = l0_lds ? (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (lds_bytes + 2048))) : kSlabsPerCu;
     unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)cus * per_cu);
     if (!l0_lds) {
-        grid = (unsigned)std::min<int64_t>(n, (int64_t)cus * 2);
+        grid = (unsigned)std::min<int64_t>(n, (int64_t)cus * kSlabsPerCu);
         p.l0_scratch = (uint32_t*)((char*)scratch + 64);
         H2GCN_HIP_TRY(hipMemsetAsync(p.l0_scratch, 0, (size_t)grid * p.l0_words * 4, stream));
     }

@@ -59,7 +59,7 @@ def test_saturating_reachability_and_self_loops():
     assert r1[1].cpu().tolist() == [1, 0, 2, 1] and r1[0].cpu().tolist() == [0, 1, 3, 4]
 
 
-@pytest.mark.parametrize("n,deg,hops", [(1, 0, 2), (64, 3, 3), (5000, 4, 3), (33000, 2.5, 4), (20000, 30, 2)])
+@pytest.mark.parametrize("n,deg,hops", [(1, 0, 2), (64, 3, 3), (5000, 4, 3), (33000, 2.5, 4), (20000, 30, 2), (200000, 3, 2)])
 def test_random_graphs_equal_host_spgemm(n, deg, hops):
     rng = np.random.default_rng(n)
     m = int(n * deg / 2)

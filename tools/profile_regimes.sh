@@ -12,3 +12,6 @@ run r02_products_d64 --d 64
 run r02_products_d100 --d 100
 run r02_products_d256 --d 256
 run r02_hbm16m_d128 --shape hbm16m
+run r02_products_d200 --d 200
+run r02_products_d512 --d 512
+run r02_products_x6_d128 --shape products_x6 --steps 5 --warmup 2
