@@ -11,7 +11,7 @@
 //   ring_k  = expand frontier F = ring_{k-1} through A, subtract ring_0 .. ring_{k-1} (ring_0 = I: sub_diag)
 //   a merged --adj_nhood group such as "0,1" = no expansion, ADD = the member rings.
 //
-// One workgroup owns one output row at a time (rows are handed out by an atomic ticket, longest-first is not needed:
+// One workgroup (256 threads; a single wave when level 0 is in global memory) owns one output row at a time (rows are handed out by an atomic ticket, longest-first is not needed:
 // the work per row is bounded by its candidate count).  The row's candidate set lives in a TWO-LEVEL BITMAP:
 //   level 0: one bit per column (n bits) -- in LDS when n <= kLdsBitmapCols, else in a per-workgroup slab of global
 //            scratch that stays L2-resident;
@@ -37,12 +37,14 @@ namespace {
 
 using h2gcn::fail;
 
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / 64;
+constexpr int kThreadsLds = 256;     // workgroup size when level 0 lives in LDS (dense rows relative to n)
+constexpr int kThreadsGlobal = 64;   // one wave per row when level 0 lives in global slabs: rows are sparse relative to n,
+                                     // latency-bound, and 4x more rows in flight per CU matter more than lanes per row
 constexpr int64_t kLdsBitmapCols = 1 << 17;  // level 0 in LDS up to this many columns (16 KiB: 8 workgroups per CU);
                                              // beyond that rows are sparse relative to n and occupancy matters more
                                              // than LDS atomics: level 0 moves to L2-resident global slabs
-constexpr int kSlabsPerCu = 8;
+constexpr int kSlabsPerCu = 32;
+constexpr size_t kMaxSlabBytes = (size_t)2 << 30;  // cap of the level-0 scratch (fewer workgroups beyond it)
 constexpr int kMaxPatterns = 8;
 
 struct Pattern {
@@ -65,6 +67,10 @@ struct RingParams {
     uint32_t* l0_scratch;     // level-0 slabs in global memory (gridDim.x * l0_words), zero-initialised; NULL = LDS
     int64_t l0_words;         // ceil(n / 32)
     int64_t l1_words;         // ceil(l0_words / 32)
+    int only_big_rows;        // bitmap kernel: serve only the rows listed in big_rows (more than kSortCap candidates;
+                              // the sorted-candidate kernel has served the others and appended these)
+    unsigned int* big_count;  // number of entries of big_rows
+    int32_t* big_rows;        // [n]
 };
 
 template <bool L0_LDS>
@@ -101,9 +107,140 @@ __device__ __forceinline__ void l0_clear(uint32_t* l0, int64_t w) {
     else __hip_atomic_store(l0 + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+constexpr int kSortCap = 1024;   // candidates per row the sorted-candidate kernel takes (LDS: 4 KiB per wave)
+constexpr int kSortWaves = 4;    // independent waves (rows) per workgroup
+
+// Number of candidates of row i = sum over its frontier nodes of deg_A(j) + lengths of the ADD rows (+1 for the
+// diagonal): what both kernels use to decide who serves the row.  Wave-uniform result.
+__device__ __forceinline__ int64_t candidate_count(const RingParams& p, int64_t i, int lane) {
+    int64_t c = 0;
+    if (p.frontier.rowptr) {
+        const int64_t fb = p.frontier.rowptr[i], fe = p.frontier.rowptr[i + 1];
+        for (int64_t f = fb + lane; f < fe; f += 64) {
+            const int64_t j = p.frontier.colidx[f];
+            c += p.a.rowptr[j + 1] - p.a.rowptr[j];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    for (int q = 0; q < p.n_add; ++q) c += p.add[q].rowptr[i + 1] - p.add[q].rowptr[i];
+    return c + (p.add_diag ? 1 : 0);
+}
+
+__device__ __forceinline__ bool pattern_row_contains(const Pattern& pat, int64_t i, int32_t c) {
+    int64_t lo = pat.rowptr[i], hi = pat.rowptr[i + 1];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int32_t v = pat.colidx[mid];
+        if (v == c) return true;
+        if (v < c) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+// Sorted-candidate kernel for SPARSE rows on wide graphs (n beyond the LDS bitmap): a 1M-bit set per row is the wrong
+// tool when the row has ~100 candidates -- every mark becomes a random DRAM read-modify-write.  Here ONE WAVE owns a
+// row: it copies the row's candidates into LDS (<= kSortCap), sorts them with a bitonic network, and emits the
+// distinct values that are in none of the SUB rows (binary search; those rows are short) in ascending order with a
+// ballot prefix.  Rows with more candidates are left to the bitmap kernel (p.only_big_rows there).
+template <bool FILL>
+__global__ __launch_bounds__(64 * kSortWaves) void ring_sorted_kernel(const RingParams p) {
+    __shared__ int32_t buf_all[kSortWaves][kSortCap];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t* buf = buf_all[wave];
+    const int64_t n_waves = (int64_t)gridDim.x * kSortWaves;
+    for (int64_t i = (int64_t)blockIdx.x * kSortWaves + wave; i < p.n; i += n_waves) {
+        const int64_t c64 = candidate_count(p, i, lane);
+        if (c64 > kSortCap) {           // the bitmap kernel serves this row
+            if (lane == 0) p.big_rows[atomicAdd(p.big_count, 1u)] = (int32_t)i;
+            continue;
+        }
+        const int c = (int)c64;
+        // ---- gather the candidates: 64 frontier nodes at a time, lane l copies the A-row of its node
+        int pos = 0;  // wave-uniform fill level
+        if (p.frontier.rowptr) {
+            const int64_t fb = p.frontier.rowptr[i], fe = p.frontier.rowptr[i + 1];
+            for (int64_t f0 = fb; f0 < fe; f0 += 64) {
+                int64_t ab = 0;
+                int deg = 0;
+                if (f0 + lane < fe) {
+                    const int64_t j = p.frontier.colidx[f0 + lane];
+                    ab = p.a.rowptr[j];
+                    deg = (int)(p.a.rowptr[j + 1] - ab);
+                }
+                int incl = deg;  // inclusive prefix sum of deg over the lanes
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int t = __shfl_up(incl, off);
+                    if (lane >= off) incl += t;
+                }
+                const int my_off = pos + incl - deg;
+                for (int t = 0; t < deg; ++t) buf[my_off + t] = p.a.colidx[ab + t];
+                pos += __shfl(incl, 63);
+            }
+        }
+        for (int q = 0; q < p.n_add; ++q) {
+            const int64_t b = p.add[q].rowptr[i];
+            const int len = (int)(p.add[q].rowptr[i + 1] - b);
+            for (int t = lane; t < len; t += 64) buf[pos + t] = p.add[q].colidx[b + t];
+            pos += len;
+        }
+        if (p.add_diag) {
+            if (lane == 0) buf[pos] = (int32_t)i;
+            pos += 1;
+        }
+        // ---- bitonic sort of the next power of two (padding = INT32_MAX, never a valid column)
+        int P = 64;
+        while (P < c) P <<= 1;
+        for (int t = c + lane; t < P; t += 64) buf[t] = 0x7fffffff;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 2; k <= P; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < (P >> 1); t += 64) {
+                    // t-th compare-exchange of this stage: partner indices (a, a ^ j) with a's j-bit clear
+                    const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int b = a | j;
+                    const int32_t va = buf[a], vb = buf[b];
+                    const bool up = (a & k) == 0;
+                    if ((va > vb) == up) {
+                        buf[a] = vb;
+                        buf[b] = va;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // ---- emit: distinct values not in any SUB row, ascending
+        int64_t out = FILL ? p.out_rowptr[i] : 0;
+        int64_t kept = 0;
+        for (int t0 = 0; t0 < c; t0 += 64) {
+            const int t = t0 + lane;
+            bool keep = false;
+            int32_t v = 0;
+            if (t < c) {
+                v = buf[t];
+                keep = (t == 0 || buf[t - 1] != v);
+                if (keep && p.sub_diag && v == (int32_t)i) keep = false;
+                for (int q = 0; keep && q < p.n_sub; ++q) keep = !pattern_row_contains(p.sub[q], i, v);
+            }
+            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+            if constexpr (FILL) {
+                if (keep) p.out_colidx[out + __builtin_popcountll(m & ((1ull << lane) - 1))] = v;
+                out += __builtin_popcountll(m);
+            }
+            kept += __builtin_popcountll(m);
+        }
+        if (!FILL && lane == 0) p.counts[i] = kept;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // FILL == false: counts[i]; FILL == true: out_colidx[out_rowptr[i] ...] in ascending order.
-template <bool L0_LDS, bool FILL>
+template <bool L0_LDS, bool FILL, int kThreads>
 __global__ __launch_bounds__(kThreads) void ring_kernel(const RingParams p) {
+    constexpr int kWaves = kThreads / 64;
     extern __shared__ uint32_t lds[];
     uint32_t* l1 = lds;                                   // [l1_words]
     uint32_t* l0 = L0_LDS ? lds + p.l1_words : p.l0_scratch + (int64_t)blockIdx.x * p.l0_words;
@@ -118,7 +255,11 @@ __global__ __launch_bounds__(kThreads) void ring_kernel(const RingParams p) {
     if (tid == 0) row_s = atomicAdd(p.ticket, 1u);
     __syncthreads();
     while (true) {
-        const int64_t i = row_s;
+        int64_t i = row_s;
+        if (p.only_big_rows) {  // tickets index the list of rows the sorted-candidate kernel left over
+            if (i >= (int64_t)__hip_atomic_load(p.big_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            i = p.big_rows[i];
+        }
         if (i >= p.n) break;
 
         // ---- mark: expansion of the frontier through A, one wave per frontier node, lanes over its neighbours
@@ -240,8 +381,10 @@ size_t h2gcn_ring_scratch_bytes(int64_t n) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int64_t l0_words = (n + 31) / 32;
-    const size_t slabs = n > kLdsBitmapCols ? (size_t)cus * kSlabsPerCu * (size_t)l0_words * 4 : 0;
-    return 64 + slabs;
+    size_t slabs = n > kLdsBitmapCols ? (size_t)cus * kSlabsPerCu * (size_t)l0_words * 4 : 0;
+    if (slabs > kMaxSlabBytes) slabs = std::max<size_t>(kMaxSlabBytes / ((size_t)l0_words * 4), 1) * (size_t)l0_words * 4;
+    const size_t big_list = n > kLdsBitmapCols ? ((size_t)n * 4 + 63) / 64 * 64 : 0;  // rows left to the bitmap kernel
+    return 64 + big_list + slabs;
 }
 
 static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_t* a_colidx, const int64_t* f_rowptr,
@@ -280,6 +423,7 @@ static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_
     p.l0_words = (n + 31) / 32;
     p.l1_words = (p.l0_words + 31) / 32;
     p.ticket = (unsigned int*)scratch;
+    p.big_count = (unsigned int*)scratch + 1;
     if (n == 0) {
         H2GCN_HIP_TRY(hipMemsetAsync(out_rowptr, 0, sizeof(int64_t), stream));
         if (nnz_out) *nnz_out = 0;
@@ -294,19 +438,25 @@ static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_
     int per_cu = l0_lds ? (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (lds_bytes + 2048))) : kSlabsPerCu;
     unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)cus * per_cu);
     if (!l0_lds) {
-        grid = (unsigned)std::min<int64_t>(n, (int64_t)cus * kSlabsPerCu);
-        p.l0_scratch = (uint32_t*)((char*)scratch + 64);
+        const size_t big_list = ((size_t)n * 4 + 63) / 64 * 64;
+        const int64_t n_slabs = (int64_t)((h2gcn_ring_scratch_bytes(n) - 64 - big_list) / ((size_t)p.l0_words * 4));
+        grid = (unsigned)std::min<int64_t>(n, n_slabs);
+        p.big_rows = (int32_t*)((char*)scratch + 64);
+        p.l0_scratch = (uint32_t*)((char*)scratch + 64 + big_list);
         H2GCN_HIP_TRY(hipMemsetAsync(p.l0_scratch, 0, (size_t)grid * p.l0_words * 4, stream));
     }
     H2GCN_HIP_TRY(hipMemsetAsync(p.ticket, 0, 64, stream));
+    const unsigned sorted_grid = (unsigned)std::min<int64_t>((n + kSortWaves - 1) / kSortWaves, (int64_t)cus * 8);
+    p.only_big_rows = l0_lds ? 0 : 1;   // wide graphs: sparse rows go to the sorted-candidate kernel
     if (!fill) {
         p.counts = out_rowptr + 1;  // counts land in out_rowptr[1..n], the scan below turns them into row pointers
         H2GCN_HIP_TRY(hipMemsetAsync(out_rowptr, 0, sizeof(int64_t), stream));
         if (l0_lds) {
-            H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)ring_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            hipLaunchKernelGGL((ring_kernel<true, false>), dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+            H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)ring_kernel<true, false, kThreadsLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL((ring_kernel<true, false, kThreadsLds>), dim3(grid), dim3(kThreadsLds), lds_bytes, stream, p);
         } else {
-            hipLaunchKernelGGL((ring_kernel<false, false>), dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+            hipLaunchKernelGGL((ring_sorted_kernel<false>), dim3(sorted_grid), dim3(64 * kSortWaves), 0, stream, p);
+            hipLaunchKernelGGL((ring_kernel<false, false, kThreadsGlobal>), dim3(grid), dim3(kThreadsGlobal), lds_bytes, stream, p);
         }
         H2GCN_HIP_TRY(hipGetLastError());
         // inclusive scan in place: out_rowptr[1..n]
@@ -325,10 +475,11 @@ static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_
         p.out_rowptr = out_rowptr;
         p.out_colidx = out_colidx;
         if (l0_lds) {
-            H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)ring_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            hipLaunchKernelGGL((ring_kernel<true, true>), dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+            H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)ring_kernel<true, true, kThreadsLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL((ring_kernel<true, true, kThreadsLds>), dim3(grid), dim3(kThreadsLds), lds_bytes, stream, p);
         } else {
-            hipLaunchKernelGGL((ring_kernel<false, true>), dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+            hipLaunchKernelGGL((ring_sorted_kernel<true>), dim3(sorted_grid), dim3(64 * kSortWaves), 0, stream, p);
+            hipLaunchKernelGGL((ring_kernel<false, true, kThreadsGlobal>), dim3(grid), dim3(kThreadsGlobal), lds_bytes, stream, p);
         }
         H2GCN_HIP_TRY(hipGetLastError());
     }

@@ -78,6 +78,33 @@ def test_random_graphs_equal_host_spgemm(n, deg, hops):
         assert np.array_equal(rings[k][0].cpu().numpy(), h.indptr) and np.array_equal(rings[k][1].cpu().numpy(), h.indices), k
 
 
+def test_wide_graph_with_hubs_mixes_sorted_and_bitmap_rows():
+    """n beyond the LDS bitmap: rows with <= 1024 candidates are served by the sorted-candidate kernel (one wave per
+    row), hub rows and their neighbours by the bitmap kernel with global level-0 slabs -- in the same result."""
+    n = 150_000
+    rng = np.random.default_rng(8)
+    m = int(1.5 * n)
+    r, c = rng.integers(0, n, m), rng.integers(0, n, m)
+    hub_nb = rng.choice(n, 5000, replace=False)
+    r = np.r_[r, np.full(5000, 77), np.full(300, 4242)]
+    c = np.r_[c, hub_nb, rng.choice(n, 300, replace=False)]
+    a = sp.csr_matrix((np.ones(2 * len(r), dtype=np.float32), (np.r_[r, c], np.r_[c, r])), shape=(n, n))
+    a = po.remove_self_loops(a)
+    a.data[:] = 1
+    a.sort_indices()
+    host = po.exact_hop_rings(a, 2)
+    rings = po.exact_hop_rings_device(torch.from_numpy(a.indptr.astype(np.int64)).to(DEV),
+                                      torch.from_numpy(a.indices.astype(np.int32)).to(DEV), n, 2)
+    for k in (1, 2):
+        h = sp.csr_matrix(host[k])
+        h.sort_indices()
+        assert np.array_equal(rings[k][0].cpu().numpy(), h.indptr) and np.array_equal(rings[k][1].cpu().numpy(), h.indices), k
+    merged = po.ring_set_device(n, torch.device(DEV), add=[rings[1], rings[2]], add_diag=True)
+    want = sp.csr_matrix(host[0] + host[1] + host[2])
+    want.sort_indices()
+    assert np.array_equal(merged[1].cpu().numpy(), want.indices)
+
+
 def test_syn_products_two_hop_ring():
     a, _, _ = load_syn_products_golden()
     adj = po.remove_self_loops(a)
