@@ -25,6 +25,8 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <type_traits>
@@ -224,15 +226,21 @@ int h2gcn_xchg_create(int world, int rank, int n_channels, size_t slot_bytes, in
         // arrival counters: fine-grained (uncached) device memory so that a store arriving over xGMI is seen by
         // a spinning wave without any cache maintenance
         const size_t flag_bytes = sizeof(uint32_t) * kMaxChannels * kMaxWorld;
+        const char* flag_kind = "uncached";
         hipError_t fe = hipExtMallocWithFlags((void**)&x->flags, flag_bytes, hipDeviceMallocUncached);
         if (fe != hipSuccess) {
             (void)hipGetLastError();
+            flag_kind = "fine-grained";
             fe = hipExtMallocWithFlags((void**)&x->flags, flag_bytes, hipDeviceMallocFinegrained);
         }
         if (fe != hipSuccess) {
             (void)hipGetLastError();
+            flag_kind = "coarse-grained (hipMalloc)";
             H2GCN_HIP_TRY(hipMalloc((void**)&x->flags, flag_bytes));
         }
+        if (getenv("H2GCN_XCHG_DEBUG"))
+            fprintf(stderr, "[h2gcn_xchg] rank %d/%d: %d channels x 2 slots of %zu bytes, mode %s, flag memory: %s\n", rank, world,
+                    n_channels, x->slot_bytes, mode == H2GCN_XCHG_COPY_ENGINE ? "copy-engine" : "copy-kernel", flag_kind);
         H2GCN_HIP_TRY(hipMemset(x->flags, 0, flag_bytes));
         H2GCN_HIP_TRY(hipHostMalloc((void**)&x->err, sizeof(int), hipHostMallocMapped));
         *x->err = 0;

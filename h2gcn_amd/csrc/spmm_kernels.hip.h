@@ -21,9 +21,11 @@
 //
 // Floating point: fp32 multiply-add per nonzero.  Inside a lane group the accumulation order is ascending
 // column order, as in the reference's CPU kernel; the G group partials (and the 4 wave partials of a long
-// segment) are then added pairwise, which is the only reordering vs. a sequential sum.  The order depends
-// only on the row's own nonzeros, never on the launch geometry, so row-partitioned multi-GPU runs reproduce
-// the single-GPU result bit-for-bit.
+// segment) are then added in a fixed tree, which is the only reordering vs. a sequential sum.  The order depends on
+// the row's own nonzeros and on two schedule parameters -- the slice width (it fixes G = 64 / (slice/4)) and the
+// long-row threshold -- never on grid geometry, rows_per_wave, the segment-walk variant or the row partition.  A
+// row-partitioned multi-GPU run that uses the same slice / feature-chunk widths therefore reproduces the single-GPU
+// result bit-for-bit; runs with different widths agree to rounding (~1e-7), not bitwise.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -5,8 +5,8 @@ Scheme: rank p owns a contiguous block of rows of every hop mat
 column ids) and the matching rows of the embedding ``X[rows_p, :]``.  ``Y[i, k, :]`` depends only on row ``i`` of
 ``A_k`` and on the rows of ``X`` its column ids name, so one exchange per layer suffices: all-gather ``X`` (RCCL
 ``ncclAllGather`` over xGMI through ``torch.distributed``, backend "nccl"), then the local fused SpMM.  The
-per-row summation order does not depend on the partitioning, so P ranks reproduce the 1-rank result
-bit-for-bit.  Everything after the aggregation in H2GCN (concat, dropout, classifier) is row-local; the backward
+per-row summation order depends on the row's own nonzeros and on the kernel's slice width, never on the partitioning,
+so P ranks reproduce the 1-rank result bit-for-bit when both use the same feature-chunk widths.  Everything after the aggregation in H2GCN (concat, dropout, classifier) is row-local; the backward
 pass needs the mirror-image reduce-scatter of ``dX``.
 
 Rows are split into equal blocks (``ceil(N/P)`` rows, last block shorter or empty) so that the all-gather is a
@@ -193,8 +193,9 @@ class PipelinedHopAggregation:
 
     The embedding is exchanged in ``n_chunks`` feature-column chunks on a side stream; the fused 1+2-hop SpMM of
     chunk ``c`` (main stream) runs while chunk ``c+1`` is still in flight over xGMI.  Output columns are
-    independent sums, so chunking changes no arithmetic: the result equals the unchunked (and the 1-GPU) result
-    bit-for-bit.  Costs: the column ids / values are re-read once per chunk (8 B per edge against ``4*d/C`` B
+    independent sums; a P-rank run equals the 1-rank run WITH THE SAME CHUNK WIDTHS bit-for-bit (the per-row summation
+    tree depends on the slice width the kernel derives from the chunk width, never on the partition); different chunk
+    widths agree to rounding (~1e-7), not bitwise.  Costs: the column ids / values are re-read once per chunk (8 B per edge against ``4*d/C`` B
     of gathered features) and the local shard is staged once into chunk-major send buffers.
 
     xGMI arithmetic: at P ranks each GPU receives ``(P-1)/P * N * d * 4`` bytes per layer over
