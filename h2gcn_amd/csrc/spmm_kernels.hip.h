@@ -739,11 +739,14 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? 4 : kMinWavesPerSimd) : 2)
     }
 }
 
-// Row-major X[n_rows, ld] -> slice-major scratch W[n_slices][n_rows][slice_cols] (d % slice_cols == 0, float4
-// granularity).  Used in front of the forward launch when the row stride of X is a multiple of 1 KiB: gathering a
-// 256-byte slice out of such rows leaves address bits 8-9 constant during a whole slice pass and the L2 / Infinity
-// Cache index only a quarter of their sets (d = 256: 0.76 of the roofline row-major, 0.91 slice-major).
-__global__ void repack_slice_major_kernel(const float* __restrict__ x, int64_t ld, int64_t n_rows, int n_slices,
+// Row-major X[n_rows, ld] -> slice-major scratch W[n_slices][n_rows][slice_cols] (n_slices = ceil(d / slice_cols),
+// float4 granularity; columns beyond d are written as zeros).  Used in front of the forward launch
+//   * when the row stride of X is a multiple of 1 KiB: gathering a 256-byte slice out of such rows leaves address
+//     bits 8-9 constant during a whole slice pass and the L2 / Infinity Cache index only a quarter of their sets
+//     (d = 256: 0.76 of the roofline row-major, 0.91 slice-major);
+//   * when the rows of X are not cache-line aligned (d = 100, 132, 200 ...): every 256-byte block of the copy is
+//     line-aligned, so a gather touches ceil(d*4/128) lines instead of one more, and the slices are cache-sized.
+__global__ void repack_slice_major_kernel(const float* __restrict__ x, int64_t ld, int64_t n_rows, int d, int n_slices,
                                           int slice_cols, float* __restrict__ w) {
     using f4 = float __attribute__((ext_vector_type(4)));
     const int c4 = slice_cols / 4;
@@ -753,7 +756,9 @@ __global__ void repack_slice_major_kernel(const float* __restrict__ x, int64_t l
         const int q = (int)(i / per_slice);
         const int64_t r = (i - q * per_slice) / c4;
         const int c = (int)(i - q * per_slice - r * c4);
-        const f4 v = *reinterpret_cast<const f4*>(x + r * ld + (int64_t)q * slice_cols + c * 4);
+        const int col = q * slice_cols + c * 4;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (col < d) v = *reinterpret_cast<const f4*>(x + r * ld + col);
         __builtin_nontemporal_store(v, reinterpret_cast<f4*>(w) + i);
     }
 }

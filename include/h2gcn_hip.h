@@ -168,7 +168,9 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
  *   of X wastes three quarters of the cache sets; the launch then first copies X into a slice-major layout inside
  *   the scratch (one streaming pass, ~3 % of the launch) and gathers from there.  h2gcn_spmm_workspace_bytes() says
  *   how much scratch such a launch wants (0 = the plain launch is already the fastest); NULL / too small simply
- *   selects the plain launch.  Results are bit-identical either way.  The scratch is only used by this launch (on
+ *   selects the plain launch.  The same copy is used when the rows of X are not cache-line aligned (ldx*4 not a
+ *   multiple of 128, e.g. d = 100, 200): its 64-column blocks are.  Results: bit-identical to the plain launch in
+ *   the 1-KiB-stride case (same slice width); equal to rounding in the unaligned case (different slice width).  The scratch is only used by this launch (on
  *   `stream`); launches that may run concurrently need separate scratch.
  * bias / H2GCN_LAUNCH_RELU: fused epilogue of the store, Y = act(A X + bias[c]) -- what SparseDense.call applies
  *   after its sparse product (reference h2gcn/models/_layers.py:45-52: `+ self.bias`, then `self.activation`), so

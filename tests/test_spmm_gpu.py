@@ -195,6 +195,37 @@ def test_slice_major_scratch_copy_is_bitwise_identical():
         assert np.abs(y_ws[r0:r0 + 8].cpu().numpy() - og.rows_subset(local, xs, list(range(8)))).max() <= ATOL
 
 
+def test_scratch_copy_for_rows_that_are_not_line_aligned():
+    """d = 200 (`--hidden 100`, second round): rows of 800 B are only 16-B aligned.  With scratch the launch gathers
+    from line-aligned 64-column blocks (slices 64, 64, 64, 8 -- the last one masked); results equal the plain launch
+    (one masked slice of 256) to rounding and the oracle on sampled rows; guard columns of a strided output untouched."""
+    from h2gcn_amd import HopPlan, _capi, synth
+
+    n, d, device = 700_000, 200, dev()
+    degs = [synth.synth_degrees(n, 12_500_000, s, n) for s in (15, 16)]
+    csr = [synth.synth_hop_rows(degs[k], n, (15, 16)[k], 0, n, device) for k in range(2)]
+    plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n)
+    x = synth.synth_features(d, 17, 0, n, device)
+    L = _capi.lib()
+    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, d, d) == n * 4 * 64 * 4      # 4 blocks of 64 columns
+    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 224, d) == 0                 # rows padded to 896 B: aligned
+    sched = plan.schedule(d)
+    assert sched["scratch_copy"] and sched["slice_cols"] == 64 and sched["n_slices"] == 4
+    ybuf = torch.full((n, 2, d + 8), 3.0, device=device)
+    y_ws = plan.spmm(x, out=ybuf[:, :, :d])
+    assert bool((ybuf[:, :, d:] == 3.0).all())
+    plan.use_workspace = False
+    y_plain = plan.spmm(x)
+    assert (y_ws - y_plain).abs().max().item() <= 2e-6
+    for r0 in (0, 4321, n - 8):
+        parts = [synth.synth_hop_rows_np(degs[k], n, (15, 16)[k], r0, r0 + 8) for k in range(2)]
+        cols = np.unique(np.concatenate([q[1] for q in parts]))
+        xs = x[torch.from_numpy(cols.astype(np.int64)).to(device)].cpu().numpy()
+        remap = {c: i for i, c in enumerate(cols)}
+        local = [(q[0], np.array([remap[c] for c in q[1]], dtype=np.int32), q[2]) for q in parts]
+        assert np.abs(y_ws[r0:r0 + 8].cpu().numpy() - og.rows_subset(local, xs, list(range(8)))).max() <= ATOL
+
+
 @pytest.mark.parametrize("d", [64, 100, 7])
 def test_fused_bias_relu_epilogue(d):
     """Y = relu(A X + b) in one launch (SparseDense.call: bias, then activation, reference _layers.py:45-52): every
