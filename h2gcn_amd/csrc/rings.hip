@@ -434,6 +434,8 @@ static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const bool l0_lds = n <= kLdsBitmapCols;
     const size_t lds_bytes = (size_t)(p.l1_words + (l0_lds ? p.l0_words : 0)) * 4;
+    if (lds_bytes > 150 * 1024)  // level 1 alone needs n / 256 bytes of LDS: ~39M columns is the limit of two levels
+        return fail(H2GCN_ERR_INVALID_ARGUMENT, "ring construction supports up to %d columns (n = %lld)", 150 * 1024 * 256, (long long)n);
     // workgroups per CU the LDS footprint allows (160 KiB per CU, keep some for the static arrays), at most 8
     int per_cu = l0_lds ? (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (lds_bytes + 2048))) : kSlabsPerCu;
     unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)cus * per_cu);
@@ -456,6 +458,7 @@ static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_
             hipLaunchKernelGGL((ring_kernel<true, false, kThreadsLds>), dim3(grid), dim3(kThreadsLds), lds_bytes, stream, p);
         } else {
             hipLaunchKernelGGL((ring_sorted_kernel<false>), dim3(sorted_grid), dim3(64 * kSortWaves), 0, stream, p);
+            H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)ring_kernel<false, false, kThreadsGlobal>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             hipLaunchKernelGGL((ring_kernel<false, false, kThreadsGlobal>), dim3(grid), dim3(kThreadsGlobal), lds_bytes, stream, p);
         }
         H2GCN_HIP_TRY(hipGetLastError());
@@ -479,6 +482,7 @@ static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_
             hipLaunchKernelGGL((ring_kernel<true, true, kThreadsLds>), dim3(grid), dim3(kThreadsLds), lds_bytes, stream, p);
         } else {
             hipLaunchKernelGGL((ring_sorted_kernel<true>), dim3(sorted_grid), dim3(64 * kSortWaves), 0, stream, p);
+            H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)ring_kernel<false, true, kThreadsGlobal>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             hipLaunchKernelGGL((ring_kernel<false, true, kThreadsGlobal>), dim3(grid), dim3(kThreadsGlobal), lds_bytes, stream, p);
         }
         H2GCN_HIP_TRY(hipGetLastError());

@@ -14,6 +14,7 @@ single fixed-count collective; the gathered buffer is padded to ``P * ceil(N/P)`
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -124,6 +125,8 @@ class IpcExchange:
         blob, err = None, None
         with torch.cuda.device(self.device):
             try:
+                if os.environ.get("H2GCN_XCHG_FAIL_ON_RANK") == str(self.rank):  # failure injection (tests): one rank's
+                    raise RuntimeError("injected set-up failure")                 # set-up fails, nobody may hang
                 _capi.check(L.h2gcn_xchg_create(self.world, self.rank, int(n_channels), int(slot_bytes),
                                                 _capi.XCHG_COPY_ENGINE if mode == "engine" else _capi.XCHG_COPY_KERNEL,
                                                 int(timeout_ms), C.byref(self._handle)))

@@ -287,3 +287,15 @@ def test_bench_two_ranks_products_shape(tmp_path):
         sums[ex] = out["config"]["y_checksum"]
         (ROOT / "gpurun_out" / f"bench_shared_gpu_products_n2_{ex}.json").write_text(json.dumps(out))
     assert sums["allgather"] == sums["ipc_engine"]
+
+
+def test_bench_survives_an_exchange_that_fails_on_one_rank(tmp_path):
+    """Failure injection: the IPC set-up fails on rank 1 only.  Construction is collectively safe -- every rank learns
+    about it through the handle exchange, the IPC candidates are rejected EVERYWHERE (with the reason in the line) and
+    the calibration goes on with the remaining exchanges; nobody waits for a rank that gave up."""
+    out = _run_bench(2, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--chunks", "2"], tmp_path,
+                     env_extra={"H2GCN_XCHG_FAIL_ON_RANK": "1", "H2GCN_BENCH_EXCHANGES": "allgather,ipc_engine,ipc_kernel"})
+    diag = out["config"]["diagnostics"]
+    assert diag["exchange"] == "allgather" and list(diag["calibration_ms_per_step"]) == ["allgather/2"]
+    assert set(diag["rejected"]) == {"ipc_engine/2", "ipc_kernel/2"}
+    assert all("IPC exchange unavailable" in v or "another rank" in v for v in diag["rejected"].values()), diag["rejected"]

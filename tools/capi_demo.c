@@ -1,6 +1,7 @@
 /* capi_demo.c -- the C ABI used from plain C, no Python / torch anywhere: what a native host (or a cgo / JNI /
- * ctypes binding) does.  Builds a 4x4 two-hop CSR by hand, runs the fused forward launch and the adjoint, and
- * checks both against values worked out by hand.
+ * ctypes binding) does.  Builds a 4x4 two-hop CSR by hand, runs the fused forward launch and the adjoint, rebuilds
+ * the 2-hop ring with the ring kernels, runs a fused bias+ReLU launch, and checks everything against values worked
+ * out by hand.
  *   hipcc -x c ... is not needed: compile as C with gcc, link libamdhip64 + libh2gcn_hip:
  *   gcc -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/capi_demo.c -o capi_demo \
  *       -L h2gcn_amd/csrc -lh2gcn_hip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../h2gcn_amd/csrc' -lm
@@ -78,6 +79,58 @@ int main(void) {
             for (int i = 0; i < N; ++i) w += A0[i][j] * y[(i * H + 0) * D + c] + A1[i][j] * y[(i * H + 1) * D + c];
             worst = fmax(worst, fabs(w - g[j * D + c]));
         }
+    /* ---- operand construction from C: exact 2-hop ring of the path graph 0-1-2-3 with the ring kernels, RW values --- */
+    {
+        const int64_t arp[N + 1] = {0, 1, 3, 5, 6};                 /* A = the path graph's pattern (= hop 0's pattern) */
+        const int64_t* d_arp = to_device(arp, sizeof arp);
+        const int32_t* d_aci = colidx[0];
+        const int64_t* sub_rp[1] = {d_arp};
+        const int32_t* sub_ci[1] = {d_aci};
+        size_t sb = h2gcn_ring_scratch_bytes(N);
+        void* scratch = NULL;
+        int64_t* ring_rp = NULL;
+        int64_t nnz2 = -1;
+        HIP(hipMalloc(&scratch, sb));
+        HIP(hipMalloc((void**)&ring_rp, sizeof(int64_t) * (N + 1)));
+        /* ring_2 = (expansion of the frontier ring_1 = A through A) minus ring_1 minus the diagonal */
+        H2(h2gcn_ring_count(N, d_arp, d_aci, d_arp, d_aci, 0, NULL, NULL, 0, 1, sub_rp, sub_ci, 1, ring_rp, &nnz2, scratch, sb, NULL));
+        int32_t* ring_ci = NULL;
+        float* ring_va = NULL;
+        HIP(hipMalloc((void**)&ring_ci, sizeof(int32_t) * (nnz2 > 0 ? nnz2 : 1)));
+        HIP(hipMalloc((void**)&ring_va, sizeof(float) * (nnz2 > 0 ? nnz2 : 1)));
+        H2(h2gcn_ring_fill(N, d_arp, d_aci, d_arp, d_aci, 0, NULL, NULL, 0, 1, sub_rp, sub_ci, 1, ring_rp, ring_ci, scratch, sb, NULL));
+        const double s_rw[3] = {0.0, 1.0, 0.5};                      /* k^-1 with inf -> 0 */
+        const double* d_tab = to_device(s_rw, sizeof s_rw);
+        H2(h2gcn_hop_normalize(N, ring_rp, ring_ci, 2 /* RW */, d_tab, 3, ring_va, NULL));
+        HIP(hipDeviceSynchronize());
+        int32_t h_ci[4];
+        float h_va[4];
+        if (nnz2 != 4) { fprintf(stderr, "2-hop ring has %lld nonzeros, expected 4\n", (long long)nnz2); return 6; }
+        HIP(hipMemcpy(h_ci, ring_ci, sizeof h_ci, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(h_va, ring_va, sizeof h_va, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 4; ++i)
+            if (h_ci[i] != ci1[i] || h_va[i] != 1.f) { fprintf(stderr, "ring entry %d: col %d val %g\n", i, h_ci[i], h_va[i]); return 6; }
+    }
+    /* ---- launch options: Y = relu(A X + b) in one launch (SparseDense.call) ---------------------------------------- */
+    {
+        const float bias[D] = {-3.f, -2.5f, 100.f, -1000.f};
+        const float* d_bias = to_device(bias, sizeof bias);
+        h2gcn_launch_opts lo;
+        memset(&lo, 0, sizeof lo);
+        lo.struct_size = sizeof lo;
+        lo.flags = H2GCN_LAUNCH_RELU;
+        lo.bias_dev = d_bias;
+        H2(h2gcn_spmm_hops_opts_f32(plan, 0x1, dx, D, D, dy, D, D, &lo, NULL));    /* hop 0 only -> [N, 1, D] */
+        HIP(hipDeviceSynchronize());
+        float y0[N * D];
+        HIP(hipMemcpy(y0, dy, sizeof y0, hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; ++i)
+            for (int c = 0; c < D; ++c) {
+                double w = bias[c];
+                for (int j = 0; j < N; ++j) w += A0[i][j] * x[j * D + c];
+                worst = fmax(worst, fabs(fmax(w, 0.0) - y0[i * D + c]));
+            }
+    }
     /* error channel: a hop mask beyond the plan must fail cleanly */
     int st = h2gcn_spmm_hops_f32(plan, 0x8, dx, D, D, dy, H * D, D, NULL);
     h2gcn_plan_destroy(plan);
