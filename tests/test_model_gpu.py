@@ -299,3 +299,41 @@ def test_sparse_dropout_network_trains(tmp_path, capsys):
     assert isinstance(model.layer_objs[0], SparseDropout)
     best = args.objects["best_val_stats"]
     assert best["val_acc"] >= 0.6 and args.objects["epoch_stats"]["train_loss"] < 1.9
+
+
+def test_citeseer_forward_matches_oracle_and_trains(tmp_path, capsys):
+    """Citeseer (reference fixture): 48 isolated nodes -> hop rows with no neighbours (the reference's inf -> 0 branch,
+    _dataset.py:115-123) and label-less rows excluded from every mask, float64 feature row-normalisation.  H2GCN-2
+    forward (device-built rings) against the numpy oracle interpreter on the golden operands, then a short training
+    run through the entry point."""
+    from test_entrypoints import _export_fixture
+    from h2gcn_amd import run_experiments
+    from h2gcn_amd.datasets._dataset import PlanetoidData
+    from h2gcn_amd.models import parse_network_setup
+    from h2gcn_amd.models.H2GCN import H2GCN
+
+    g = load_planetoid_golden("citeseer")
+    _export_fixture(g, tmp_path, "ind.citeseer")
+    data = PlanetoidData("ind.citeseer", tmp_path, val_size=500)
+    data.row_normalize_features()
+    data.adj_remove_eye()
+    dev = torch.device("cuda:0")
+    tensors = data.get_tensors(dev, adj_norm_hops=["1", "2"])
+    assert tensors["adj_hops"].nnz == [9104, 37826]                      # SURVEY.md §8c: nnz per split [3327, 9104, 37826]
+    setup = parse_network_setup(H2GCN2, data.num_labels, _dense_units=64, _dropout_rate=0.5)
+    torch.manual_seed(3)
+    model = H2GCN(setup, input_dim=tensors["features"].n_cols, n_hops=2, l2_regularize_weight=5e-4).to(dev).eval()
+    tagged = {}
+    with torch.no_grad():
+        logits = model(tensors["adj"], tensors["features"], tensors["adj_hops"], tagged_out=tagged)
+    weights = [l.kernel.detach().cpu().numpy() for l in model.regularized]
+    want, want_tagged, _ = om.forward(_enc(setup), g["feat_rownorm"], [g["hop1_sym"], g["hop2_sym"]], weights, return_tagged=True)
+    assert np.abs(logits.cpu().numpy() - want).max() <= 1e-5
+    for name, v in want_tagged.items():
+        assert np.abs(tagged[name].cpu().numpy() - v).max() <= 1e-5, name
+    empty2 = np.diff(g["hop2_sym"].indptr) == 0
+    assert empty2.sum() == 653 and not tagged["2"][torch.from_numpy(empty2).to(dev)][:, 64:].any().item()   # zero rows stay zero
+    args = run_experiments.main(["H2GCN", "planetoid", "--dataset", "ind.citeseer", "--dataset_path", str(tmp_path),
+                                 "--epochs", "60", "--random_seed", "123"])
+    best = args.objects["best_val_stats"]
+    assert best["val_acc"] >= 0.55 and np.isfinite(args.objects["epoch_stats"]["train_loss"])
