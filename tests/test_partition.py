@@ -138,7 +138,7 @@ def _worker(rank, world, port, n, d, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 1000), (3, 1001)])
+@pytest.mark.parametrize("world,n", [(2, 1000), (3, 1001), (8, 1003)])
 def test_row_partition_allgather_equals_single_rank(world, n, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n, 16, str(tmp_path)), nprocs=world, join=True)
