@@ -37,6 +37,10 @@ def test_abi_version_and_error_channel():
                       ("H2GCN_ERR_BAD_INDEX", -4), ("H2GCN_ERR_NO_TRANSPOSE", -5)):
         assert re.search(rf"{name}\s*=\s*{val}\b", text)
     assert ctypes.sizeof(_capi.PlanOpts) == 32
+    for name, val in (("H2GCN_ERR_INTERNAL", -6), ("H2GCN_ERR_EXCHANGE_TIMEOUT", -7)):
+        assert re.search(rf"{name}\s*=\s*{val}\b", text)
+    assert ctypes.sizeof(_capi.LaunchOpts) == 32 and _capi.XCHG_BLOB_BYTES == int(re.search(r"H2GCN_XCHG_BLOB_BYTES\s+(\d+)", text).group(1))
+    assert int(re.search(r"#define H2GCN_ABI_VERSION\s+(\d+)", text).group(1)) == _capi.ABI_VERSION
 
 
 def test_null_plan_is_an_error_not_a_crash():
@@ -47,6 +51,17 @@ def test_null_plan_is_an_error_not_a_crash():
     with pytest.raises(_capi.H2GCNError):
         _capi.check(st)
     L.h2gcn_plan_destroy(None)  # no-op
+    # the entry points added in ABI 2 validate their arguments before touching the device as well
+    assert L.h2gcn_spmm_hops_opts_f32(None, 0, None, 0, 1, None, 0, 0, None, None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.h2gcn_plan_schedule(None, 0, 0, 1, 1, None, None, None, None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.h2gcn_plan_set_values(None, 0, None, None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.h2gcn_spmm_workspace_bytes(None, 0, 1, 1) == 0
+    assert L.h2gcn_ring_count(-1, None, None, None, None, 0, None, None, 0, 0, None, None, 0, None, None, None, 0, None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.h2gcn_hop_normalize(4, None, None, 1, None, 0, None, None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.h2gcn_xchg_status(None) == _capi.ERR_INVALID_ARGUMENT and L.h2gcn_xchg_allgather_end(None, 0, None) == _capi.ERR_INVALID_ARGUMENT
+    out = ctypes.c_void_p()
+    assert L.h2gcn_xchg_create(0, 0, 1, 64, 0, 0, ctypes.byref(out)) == _capi.ERR_INVALID_ARGUMENT and not out.value
+    L.h2gcn_xchg_destroy(None)  # no-op
 
 
 def test_product_path_has_no_cpu_fallback():
