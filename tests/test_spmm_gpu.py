@@ -645,9 +645,9 @@ def test_errors_are_python_exceptions_before_or_at_the_c_call():
 
 
 # ----------------------------------------------------------------------------- BASELINE shapes, size-independent properties
-@pytest.mark.parametrize("shape", ["arxiv", "products"])
+@pytest.mark.parametrize("shape", ["arxiv", "products", "lowdeg"])
 def test_baseline_shapes_properties(shape):
-    """configs[2] / configs[3] at FULL size: (1) row-stochastic hops map the all-ones features to ones on every
+    """configs[2] / configs[3] at FULL size (+ the mean-degree-4 stress shape, which runs the short-row kernels): (1) row-stochastic hops map the all-ones features to ones on every
     non-empty row and zeros on empty rows; (2) linearity; (3) sampled rows against the fp64 oracle, the CPU
     regenerating those rows of the operands independently (counter-based generator)."""
     from h2gcn_amd import HopPlan, synth
