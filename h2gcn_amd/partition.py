@@ -451,10 +451,12 @@ class ShardedHops:
     aggregates; its backward is the shard adjoint followed by a reduce-scatter."""
 
     def __init__(self, plan, n_global: int, device, group: Optional[dist.ProcessGroup] = None, chunk_cols: int = 32,
-                 max_chunks: int = 4):
+                 max_chunks: int = 4, exchange: Optional[str] = None):
+        #: "allgather" (RCCL) | "p2p" | "ipc_engine" | "ipc_kernel"; default from $H2GCN_EXCHANGE, else "allgather"
+        self.exchange = exchange or os.environ.get("H2GCN_EXCHANGE", "allgather")
         self.plan = plan
         self.n_global = int(n_global)
-        self.device = device
+        self.device = torch.device(device)
         self.group = group
         self.chunk_cols, self.max_chunks = int(chunk_cols), int(max_chunks)
         self.n_hops, self.n_rows, self.n_cols = plan.n_hops, plan.n_rows, plan.n_cols
@@ -465,7 +467,8 @@ class ShardedHops:
             chunks = 1
             while chunks * 2 <= self.max_chunks and d % (chunks * 2) == 0 and d // (chunks * 2) >= self.chunk_cols:
                 chunks *= 2
-            self._pipes[d] = PipelinedHopAggregation(self.plan, self.n_global, d, chunks, self.device, self.group)
+            self._pipes[d] = PipelinedHopAggregation(self.plan, self.n_global, d, chunks, self.device, self.group,
+                                                     exchange=self.exchange if self.device.type == "cuda" or not self.exchange.startswith("ipc_") else "allgather")
         return self._pipes[d]
 
     def aggregate(self, x_local: torch.Tensor, hops=None) -> torch.Tensor:

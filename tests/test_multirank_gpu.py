@@ -99,9 +99,12 @@ if int(os.environ.get("RANK", "0")) == 0:
 '''
 
 
-@pytest.mark.parametrize("network", ["M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO",          # H2GCN-2: concat-free sharded propagation
-                                     "M64-R-T1-G0-V-T2-G0_1-V-C1_2-D0.0-MO"])     # hop filters on the shards
-def test_row_partitioned_training_matches_single_process(tmp_path, network):
+@pytest.mark.parametrize("network,exchange", [
+    ("M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", "allgather"),        # H2GCN-2: concat-free sharded propagation
+    ("M64-R-T1-G0-V-T2-G0_1-V-C1_2-D0.0-MO", "allgather"),     # hop filters on the shards
+    ("M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", "ipc_engine"),       # the same with the library's own IPC all-gather
+])
+def test_row_partitioned_training_matches_single_process(tmp_path, network, exchange):
     """`run_experiments` under torch.distributed (2 ranks, rows of features / hop matrices / labels partitioned,
     dense kernels replicated, all-gather forward, reduce-scatter + gradient all-reduce backward) follows the
     single-process training trajectory.  Dropout is disabled so both runs are deterministic."""
@@ -117,7 +120,7 @@ def test_row_partitioned_training_matches_single_process(tmp_path, network):
         procs = []
         out_file = tmp_path / f"stats{world}.json"
         for rank in range(world):
-            env = dict(os.environ, H2GCN_ROOT=str(ROOT), DATA_DIR=str(data_dir), OUT_FILE=str(out_file), NETWORK=network)
+            env = dict(os.environ, H2GCN_ROOT=str(ROOT), DATA_DIR=str(data_dir), OUT_FILE=str(out_file), NETWORK=network, H2GCN_EXCHANGE=exchange)
             if world > 1:
                 env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                            MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1")
