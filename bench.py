@@ -235,7 +235,9 @@ def main():
     else:
         exchanges = [a.exchange] if a.exchange else os.environ.get(
             "H2GCN_BENCH_EXCHANGES", "allgather,p2p,ipc_engine,ipc_kernel").split(",")
-        chunk_specs = [a.chunks] if a.chunks else ["1", "2", "4", "32+32+64"]
+        # "32+32+64": short exposed head when the step is compute-bound; "64+32+32": short exposed tail (the last SpMM) when it
+        # is exchange-bound -- which of the two regimes a node is in is exactly what is being measured
+        chunk_specs = [a.chunks] if a.chunks else ["1", "2", "4", "32+32+64", "64+32+32"]
         cands = {}
         for ex in exchanges:
             for spec in chunk_specs:
