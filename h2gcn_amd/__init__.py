@@ -15,7 +15,7 @@ C ABI of ``include/h2gcn_hip.h``).  It mirrors the reference's operator interfac
 There is no CPU fallback: every compute entry point raises if the HIP library or a GPU is missing.
 """
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 from . import _capi  # noqa: F401  (does not load the library until first use)
 from .hops import HopPlan  # noqa: F401
