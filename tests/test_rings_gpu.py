@@ -134,3 +134,64 @@ def test_more_than_2_20_columns_uses_the_global_bitmap():
     want = sp.csr_matrix(po.normalize_hop(host[2], po.SYM_NORMALIZED))
     want.sort_indices()
     assert np.array_equal(vals, want.data.astype(np.float32))
+
+
+def test_set_algebra_entry_points_directly():
+    """h2gcn_ring_count / _fill as a general row-set algebra: unions, differences, the diagonal, empty operands,
+    n = 0, and the scratch-size check -- against Python sets."""
+    import ctypes as C
+
+    from h2gcn_amd import _capi
+
+    dev = torch.device(DEV)
+    rng = np.random.default_rng(4)
+    n = 257
+
+    def rand_pattern(density):
+        m = sp.random(n, n, density, format="csr", random_state=int(rng.integers(1 << 30)), dtype=np.float32)
+        m.sort_indices()
+        return m, (torch.from_numpy(m.indptr.astype(np.int64)).to(dev), torch.from_numpy(m.indices.astype(np.int32)).to(dev))
+
+    (ma, a), (mf, f), (mb, b), (mc, c) = rand_pattern(0.03), rand_pattern(0.02), rand_pattern(0.05), rand_pattern(0.04)
+
+    def rows(m):
+        return [set(m.indices[m.indptr[i]:m.indptr[i + 1]].tolist()) for i in range(n)]
+
+    ra, rf, rb, rc = rows(ma), rows(mf), rows(mb), rows(mc)
+
+    def check(got, want):
+        rp, ci = got[0].cpu().numpy(), got[1].cpu().numpy()
+        for i in range(n):
+            assert ci[rp[i]:rp[i + 1]].tolist() == sorted(want[i]), i
+
+    expand = [set().union(*[ra[j] for j in rf[i]]) if rf[i] else set() for i in range(n)]
+    check(po.ring_set_device(n, dev, a=a, frontier=f), expand)
+    check(po.ring_set_device(n, dev, a=a, frontier=f, add=[b], add_diag=True, sub=[c]),
+          [(expand[i] | rb[i] | {i}) - rc[i] for i in range(n)])
+    check(po.ring_set_device(n, dev, add=[b, c]), [rb[i] | rc[i] for i in range(n)])
+    check(po.ring_set_device(n, dev, add=[b], sub=[b]), [set() for _ in range(n)])
+    check(po.ring_set_device(n, dev, add_diag=True, sub=[c]), [{i} - rc[i] for i in range(n)])
+    check(po.ring_set_device(n, dev, add=[b], sub=[c], sub_diag=True), [rb[i] - rc[i] - {i} for i in range(n)])
+    empty = po.ring_set_device(0, dev)
+    assert empty[0].tolist() == [0] and empty[1].numel() == 0
+    # too little scratch is an error, not a crash
+    L = _capi.lib()
+    rp = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    nnz = C.c_int64()
+    tiny = torch.empty(8, dtype=torch.uint8, device=dev)
+    st = L.h2gcn_ring_count(n, None, None, None, None, 0, None, None, 1, 0, None, None, 0, C.c_void_p(rp.data_ptr()), C.byref(nnz),
+                            C.c_void_p(tiny.data_ptr()), 8, None)
+    assert st == _capi.ERR_INVALID_ARGUMENT and b"scratch" in L.h2gcn_last_error()
+    # three exact rings of a path graph with a pendant triangle, through the public builder
+    edges = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 3)]
+    m = sp.lil_matrix((6, 6), dtype=np.float32)
+    for u, v in edges:
+        m[u, v] = m[v, u] = 1
+    m = sp.csr_matrix(m)
+    m.sort_indices()
+    host = po.exact_hop_rings(m, 3)
+    rings = po.exact_hop_rings_device(torch.from_numpy(m.indptr.astype(np.int64)).to(dev), torch.from_numpy(m.indices.astype(np.int32)).to(dev), 6, 3)
+    for k in range(4):
+        h = sp.csr_matrix(host[k])
+        h.sort_indices()
+        assert rings[k][1].cpu().tolist() == h.indices.tolist(), k
