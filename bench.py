@@ -88,6 +88,18 @@ def cpu_baseline(plan_csr, x_full, d, target_seconds=12.0):
                   f"oracle/spmm_oracle.c (plain C, -O2, 1 thread; host has {os.cpu_count()} cores)",
         "calibration_edges_per_s": rate,
     }
+    # the same C loop with the output rows spread over all host cores (OpenMP; identical bits) -- an upper bound on what
+    # a parallelised build of the reference's CPU kernel could do on this host
+    try:
+        threads = len(os.sched_getaffinity(0))
+        og.gcn_layer_c(parts, x_cpu, threads=True)  # warm-up (thread pool)
+        t = time.perf_counter()
+        og.gcn_layer_c(parts, x_cpu, threads=True)
+        dt3 = time.perf_counter() - t
+        res["port_all_cores"] = {"value": edges / dt3, "unit": "edges/s", "cores": threads, "seconds": dt3,
+                                 "what": "oracle_gcn_layer_f32_mt (OpenMP over output rows), same sample"}
+    except Exception as e:  # noqa: BLE001
+        res["port_all_cores"] = {"value": None, "error": str(e)}
     # second reported baseline (SURVEY.md §8d ii): torch's CPU CSR @ dense on all host threads, same sample
     try:
         xt = torch.from_numpy(x_cpu)

@@ -52,7 +52,8 @@ def _ptr_array(arrs, ctype):
     return (C.c_void_p * len(arrs))(*[a.ctypes.data_as(C.c_void_p) for a in arrs])
 
 
-def gcn_layer_c(hops, x, fma=False):
+def gcn_layer_c(hops, x, fma=False, threads=False):
+    """``threads=True``: the OpenMP variant (rows spread over all host cores, identical bits)."""
     parts = [_csr_parts(m) for m in hops]
     x = np.ascontiguousarray(x, dtype=np.float32)
     n_rows = len(parts[0][0]) - 1
@@ -61,7 +62,7 @@ def gcn_layer_c(hops, x, fma=False):
     y = np.empty((n_rows, H, d), dtype=np.float32)
     L = _lib()
     if not fma:
-        L.oracle_gcn_layer_f32(C.c_int(H), C.c_int64(n_rows), _ptr_array([p[0] for p in parts], None),
+        (L.oracle_gcn_layer_f32_mt if threads else L.oracle_gcn_layer_f32)(C.c_int(H), C.c_int64(n_rows), _ptr_array([p[0] for p in parts], None),
                                _ptr_array([p[1] for p in parts], None), _ptr_array([p[2] for p in parts], None),
                                x.ctypes.data_as(C.c_void_p), C.c_int64(x.shape[1]), C.c_int64(d),
                                y.ctypes.data_as(C.c_void_p))

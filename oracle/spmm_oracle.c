@@ -91,6 +91,23 @@ void oracle_gcn_layer_f32(int n_hops, int64_t n_rows, const int64_t* const* rowp
         oracle_spmm_csr_f32(n_rows, rowptr[k], colidx[k], vals[k], x, ldx, d, y + (int64_t)k * d, (int64_t)n_hops * d);
 }
 
+/* The same layer with the output rows spread over OpenMP threads (per-row arithmetic unchanged: identical bits).  Only
+ * for the "all host cores" CPU baseline of bench.py -- TensorFlow's own CPU kernel is single-threaded. */
+void oracle_gcn_layer_f32_mt(int n_hops, int64_t n_rows, const int64_t* const* rowptr, const int32_t* const* colidx,
+                             const float* const* vals, const float* x, int64_t ldx, int64_t d, float* y) {
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < n_rows; ++i)
+        for (int k = 0; k < n_hops; ++k) {
+            float* o = y + (i * n_hops + k) * d;
+            memset(o, 0, (size_t)d * sizeof(float));
+            for (int64_t e = rowptr[k][i]; e < rowptr[k][i + 1]; ++e) {
+                const float a = vals[k][e];
+                const float* br = x + (int64_t)colidx[k][e] * ldx;
+                for (int64_t c = 0; c < d; ++c) o[c] = o[c] + a * br[c];
+            }
+        }
+}
+
 /* (a4) dX[j, :] = sum_k sum_i A_k[i, j] * dY[i, k, :]; accumulation order: hop-major, then row-major stored
  * order (what unstacking + one adjoint SpMM per hop + add_n gives). */
 void oracle_gcn_layer_grad_f32(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t* const* rowptr,

@@ -135,3 +135,15 @@ def test_oracle_agrees_with_an_independent_implementation():
                                     torch.from_numpy(m.data.astype(np.float32)), size=m.shape)
         got = (t @ torch.from_numpy(x)).numpy()
         assert np.abs(got - og.gcn_layer_c([m], x)[:, 0, :]).max() <= 2e-6
+
+
+def test_threaded_oracle_layer_has_identical_bits():
+    """oracle_gcn_layer_f32_mt (bench.py's all-cores CPU baseline) only spreads output rows over threads."""
+    import scipy.sparse as sp
+
+    from oracle import gcn_layer as og
+
+    rng = np.random.default_rng(3)
+    hops = [sp.random(3000, 2000, 0.01, format="csr", random_state=k, dtype=np.float32) for k in range(3)]
+    x = rng.uniform(-1, 1, (2000, 48)).astype(np.float32)
+    assert np.array_equal(og.gcn_layer_c(hops, x), og.gcn_layer_c(hops, x, threads=True))
