@@ -7,10 +7,11 @@ C ABI of ``include/h2gcn_hip.h``).  It mirrors the reference's operator interfac
   (reference ``h2gcn/models/_layers.py:54-81``);
 * :class:`h2gcn_amd.hops.HopPlan` -- the device-resident ``adj_hops`` operand list
   (reference ``h2gcn/datasets/_dataset.py:559-576``);
-* :mod:`h2gcn_amd.operands` -- host-side construction of the normalised exact-k-hop matrices
+* :mod:`h2gcn_amd.operands` -- construction of the normalised exact-k-hop matrices: on the device with the HIP ring
+  kernels (``build_adj_norm_hops_device``) or on the host with scipy as the reference does
   (reference ``h2gcn/datasets/_dataset.py:102-158``);
-* :mod:`h2gcn_amd.partition` -- row partitioning + RCCL all-gather for 1..8 GPUs (new; the reference is
-  single-device).
+* :mod:`h2gcn_amd.partition` -- row partitioning + embedding exchange (RCCL all-gather or the library's IPC pulls) for
+  1..8 GPUs (new; the reference is single-device).
 
 There is no CPU fallback: every compute entry point raises if the HIP library or a GPU is missing.
 """
@@ -19,4 +20,4 @@ __version__ = "0.2.0"
 
 from . import _capi  # noqa: F401  (does not load the library until first use)
 from .hops import HopPlan  # noqa: F401
-from .layers import ConcatLayer, GCNLayer, SliceLayer, SparseDense, hop_spmm  # noqa: F401
+from .layers import ConcatLayer, GCNLayer, SliceLayer, SparseDense, SparseDropout, hop_spmm  # noqa: F401
