@@ -475,7 +475,6 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? 4 : kMinWavesPerSimd) : 2)
 
     if constexpr (SHORT && EXACT && (kWave / LPR == 2 || kWave / LPR == 4)) {
         constexpr int G = kWave / LPR;
-        const int group_lane0 = lane & ~(LPR - 1);
         const int short_max = min(LPR, p.long_threshold - 1);
         const int n_blocks = (rows_here + G - 1) / G;       // row blocks of G consecutive rows
         const GatherAddr<OFF32> addr0{nullptr, (off_t)(li_src * VEC * 4), (off_t)(p.ld_src * 4)};
@@ -634,7 +633,6 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? 4 : kMinWavesPerSimd) : 2)
                 cur_short = nxt_short;
             }
         }
-        (void)group_lane0;
         return;
     }
 
