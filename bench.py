@@ -134,6 +134,54 @@ def probe_ceilings(table_mib, row_bytes):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def measure_traffic_live(a, timeout_s=240):
+    """HBM-side bytes per forward launch measured on THIS box: two short child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, kernel-trace only -- MI355X_MICROARCH.md 'HBM');
+    traffic = 2 x FETCH_SIZE x 1024 (gfx950 counts half of a wide coalesced read) + WRITE_SIZE x 1024, averaged over
+    the forward launches.  Returns None when rocprofv3 is unavailable or the pass fails (the line then falls back to
+    the committed offline profile and says so)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not Path(exe).exists() or os.environ.get("H2GCN_BENCH_CHILD") == "1":
+        return None
+    pat = re.compile(r"spmm_hops_kernel<\d+, \d+, (?:true|false), false")   # forward launches (SUM = false)
+    child = [sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-probe",
+             "--no-adjoint", "--no-traffic", "--shape", a.shape, "--variant", str(a.variant)]
+    for flag, val in (("--d", a.d), ("--slice-cols", a.slice_cols), ("--long-row-threshold", a.long_row_threshold),
+                      ("--rows-per-wave", a.rows_per_wave)):
+        if val:
+            child += [flag, str(val)]
+    if a.chunks:
+        child += ["--chunks", a.chunks]
+    out = {}
+    try:
+        import pandas as pd
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                env = dict(os.environ, TMPDIR="/tmp", H2GCN_BENCH_CHILD="1")
+                r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", td, "-o", "t", "--"] + child,
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+                files = list(Path(td).rglob("*counter_collection.csv"))
+                if r.returncode != 0 or not files:
+                    return None
+                df = pd.read_csv(files[0])
+                df = df[df.Kernel_Name.map(lambda k: bool(pat.search(k)))]
+                if df.empty:
+                    return None
+                out[counter] = float(df.groupby("Dispatch_Id").Counter_Value.sum().mean())
+    except Exception:  # noqa: BLE001 -- a report, never a reason to lose the GPU number
+        return None
+    launches_per_step = len(a.chunks.split("+")) if "+" in a.chunks else int(a.chunks or 1)
+    return {"bytes_per_launch": (2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024 * launches_per_step,
+            "read_bytes": 2 * out["FETCH_SIZE"] * 1024 * launches_per_step, "write_bytes": out["WRITE_SIZE"] * 1024 * launches_per_step,
+            "source": "LIVE: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command on this box "
+                      "(2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 per step; FETCH_SIZE counts L2 misses, i.e. Infinity-Cache hits too)"}
+
+
 def parse_chunks(spec, d):
     """'2' -> 2 equal chunks; '32+32+64' -> explicit widths."""
     spec = str(spec)
@@ -160,6 +208,7 @@ def main():
     ap.add_argument("--no-adjoint", action="store_true", help="skip the (untimed, secondary) adjoint launch figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the live gather/copy ceiling probe")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
 
@@ -398,6 +447,14 @@ def main():
                           "frac": b_adj / (adj.mean() * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                           "edges_per_s": sum(nnz_local) / (adj.mean() * 1e-3)}
         del dy
+    if rank == 0 and world == 1 and not a.no_traffic:
+        # release the big operands of this process first? no: the child generates its own; 288 GB hold both
+        live = measure_traffic_live(a)
+        if live is not None:
+            out["roofline"]["traffic"] = live["bytes_per_launch"]
+            out["roofline"]["traffic_source"] = live["source"]
+            out["roofline"]["traffic_read_bytes"], out["roofline"]["traffic_write_bytes"] = live["read_bytes"], live["write_bytes"]
+            out["roofline"]["traffic_over_algorithmic"] = live["bytes_per_launch"] / b_alg
     if rank == 0 and world == 1 and not a.no_probe:
         # live ceilings of this box at the kernel's gather working set (one column slice of X)
         slice_cols = min(plan.schedule(d)["slice_cols"], d)

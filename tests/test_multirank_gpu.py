@@ -248,7 +248,7 @@ def _run_bench(world, extra, tmp_path, env_extra=None):
                 env.pop(k, None)
         env.update(env_extra or {})
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--no-cpu-baseline",
-                                       "--no-probe"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+                                       "--no-probe", "--no-traffic"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
     outs = [p.communicate(timeout=1500) for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[1].decode()[-3000:] for o in outs)
     lines = [l for l in outs[0][0].decode().splitlines() if l.startswith("{")]

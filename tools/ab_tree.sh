@@ -4,5 +4,5 @@
 OUT=$1; shift; : > $OUT
 for round in 1 2 3; do for tree in build/ab/old .; do
 echo -n "$tree round=$round " >> $OUT
-(cd $tree && timeout 300 python bench.py --no-cpu-baseline --no-probe --no-adjoint --steps 20 --warmup 5 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms'])") >> $OUT 2>&1
+(cd $tree && H2GCN_BENCH_CHILD=1 timeout 300 python bench.py --no-cpu-baseline --no-probe --no-adjoint --steps 20 --warmup 5 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms'])") >> $OUT 2>&1
 done; done; cat $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 OUT=$1; : > $OUT
-run() { echo "## $*" >> $OUT; timeout 600 python bench.py --no-cpu-baseline --no-probe --steps 10 --warmup 3 "$@" 2>/dev/null | tail -1 | python -c "
+run() { echo "## $*" >> $OUT; timeout 600 python bench.py --no-cpu-baseline --no-probe --no-traffic --steps 10 --warmup 3 "$@" 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; a=d.get('adjoint',{})
 print(json.dumps({'walk':d['config']['schedule']['segment_walk'],'slice':d['config']['schedule']['slice_cols'],'kernel_ms':round(r['kernel_ms'],4),'frac':round(r['frac'],4),'adjoint_ms':round(a.get('kernel_ms',0),4),'adjoint_frac':round(a.get('frac',0),4)}))" >> $OUT 2>&1; }
 for shape in lowdeg hbm16m; do run --shape $shape --variant 3; run --shape $shape; run --shape $shape --slice-cols 64;  run --shape $shape --variant 3; run --shape $shape; done
