@@ -148,6 +148,8 @@ def measure_traffic_live(a, timeout_s=240):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not Path(exe).exists() or os.environ.get("H2GCN_BENCH_CHILD") == "1":
         return None
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) or k in ("HSA_TOOLS_LIB", "LD_PRELOAD") for k in os.environ):
+        return None  # this process is itself being profiled / instrumented: do not nest a profiler under it
     pat = re.compile(r"spmm_hops_kernel<\d+, \d+, (?:true|false), false")   # forward launches (SUM = false)
     child = [sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-probe",
              "--no-adjoint", "--no-traffic", "--shape", a.shape, "--variant", str(a.variant)]
