@@ -111,6 +111,17 @@ __global__ void wait_kernel(const uint32_t* flag, uint32_t seq, long long timeou
     if (threadIdx.x == 0) wait_flag(flag, seq, timeout_ticks, err);
 }
 
+// out[i] = sum over ranks q = 0 .. world-1 (ascending: a fixed order, the result does not depend on arrival order) of
+// block q, where block `rank` is this rank's own contribution and the others arrived in recv[q]
+__global__ void sum_blocks_kernel(const float* __restrict__ recv, const float* __restrict__ own, int world, int rank,
+                                  size_t block_elems, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < block_elems; i += (size_t)gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int q = 0; q < world; ++q) acc += (q == rank) ? own[i] : recv[(size_t)q * block_elems + i];
+        out[i] = acc;
+    }
+}
+
 // Copy-kernel pulls: block b serves peer slot b / kPullBlocksPerPeer (the peers other than `rank`, in order).
 __global__ __launch_bounds__(kPullThreads) void pull_kernel(PeerTable peers, const uint32_t* my_flags, int world, int rank,
                                                             int channel, uint32_t seq, size_t slot_off, size_t bytes,
@@ -169,7 +180,12 @@ struct h2gcn_xchg {
     std::vector<hipEvent_t> pulled;     // [n_channels * world]
     std::vector<char> pulled_valid;     // event has been recorded at least once
     std::vector<uint32_t> seq;          // [n_channels]
-    std::vector<char> open_channel;     // begin without end
+    std::vector<char> open_channel;     // begin without end (1 = all-gather, 2 = reduce-scatter)
+    // reduce-scatter state per channel: receive buffer (world blocks) and what `end` has to sum
+    std::vector<float*> rs_recv;
+    std::vector<size_t> rs_recv_bytes;
+    struct RsPending { float* out; const float* own; size_t block_elems; };
+    std::vector<RsPending> rs_pending;
 };
 
 namespace {
@@ -185,10 +201,41 @@ void release(h2gcn_xchg* x) {
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : x->streams)
         if (s) (void)hipStreamDestroy(s);
+    for (float* r : x->rs_recv)
+        if (r) (void)hipFree(r);
     if (x->data) (void)hipFree(x->data);
     if (x->flags) (void)hipFree(x->flags);
     if (x->err) (void)hipHostFree(x->err);
     delete x;
+}
+
+// Pull `bytes` from every peer q -- its exported memory at offset `src_off` -- into dst + q * bytes, after the peer has
+// announced sequence number `seq` on `channel`; records this channel's pull events.
+int issue_pulls(h2gcn_xchg* x, int channel, uint32_t seq, size_t src_off, size_t bytes, char* dst) {
+    if (x->mode == H2GCN_XCHG_COPY_KERNEL) {
+        hipStream_t cs = x->streams[x->rank];
+        H2GCN_HIP_TRY(hipStreamWaitEvent(cs, x->fence[channel], 0));
+        hipLaunchKernelGGL(pull_kernel, dim3((x->world - 1) * kPullBlocksPerPeer), dim3(kPullThreads), 0, cs, x->peers,
+                           (const uint32_t*)x->flags, x->world, x->rank, channel, seq, src_off, bytes, dst, x->timeout_ticks, x->err);
+        H2GCN_HIP_TRY(hipGetLastError());
+        const size_t ei = (size_t)channel * x->world + x->rank;
+        H2GCN_HIP_TRY(hipEventRecord(x->pulled[ei], cs));
+        x->pulled_valid[ei] = 1;
+    } else {
+        for (int shift = 1; shift < x->world; ++shift) {
+            const int q = (x->rank + shift) % x->world;  // start with a different peer on every rank
+            hipStream_t ps = x->streams[q];
+            H2GCN_HIP_TRY(hipStreamWaitEvent(ps, x->fence[channel], 0));
+            hipLaunchKernelGGL(wait_kernel, dim3(1), dim3(64), 0, ps, (const uint32_t*)(x->flags + channel * kMaxWorld + q), seq,
+                               x->timeout_ticks, x->err);
+            H2GCN_HIP_TRY(hipGetLastError());
+            H2GCN_HIP_TRY(hipMemcpyAsync(dst + (size_t)q * bytes, x->peers.data[q] + src_off, bytes, hipMemcpyDeviceToDevice, ps));
+            const size_t ei = (size_t)channel * x->world + q;
+            H2GCN_HIP_TRY(hipEventRecord(x->pulled[ei], ps));
+            x->pulled_valid[ei] = 1;
+        }
+    }
+    return H2GCN_OK;
 }
 
 }  // namespace
@@ -260,6 +307,9 @@ int h2gcn_xchg_create(int world, int rank, int n_channels, size_t slot_bytes, in
         x->pulled_valid.assign((size_t)n_channels * world, 0);
         x->seq.assign(n_channels, 0);
         x->open_channel.assign(n_channels, 0);
+        x->rs_recv.assign(n_channels, nullptr);
+        x->rs_recv_bytes.assign(n_channels, 0);
+        x->rs_pending.assign(n_channels, h2gcn_xchg::RsPending{nullptr, nullptr, 0});
         x->peers.data[rank] = x->data;
         x->peers.flags[rank] = x->flags;
         x->connected = (world == 1);
@@ -367,32 +417,7 @@ int h2gcn_xchg_allgather_begin(h2gcn_xchg_t* x, int channel, const float* src, i
         x->open_channel[channel] = 1;
         if (x->world == 1 || bytes == 0) return H2GCN_OK;
 
-        if (x->mode == H2GCN_XCHG_COPY_KERNEL) {
-            hipStream_t cs = x->streams[x->rank];
-            H2GCN_HIP_TRY(hipStreamWaitEvent(cs, x->fence[channel], 0));
-            hipLaunchKernelGGL(pull_kernel, dim3((x->world - 1) * kPullBlocksPerPeer), dim3(kPullThreads), 0, cs, x->peers,
-                               (const uint32_t*)x->flags, x->world, x->rank, channel, seq, slot_off, bytes, (char*)full,
-                               x->timeout_ticks, x->err);
-            H2GCN_HIP_TRY(hipGetLastError());
-            const size_t ei = (size_t)channel * x->world + x->rank;
-            H2GCN_HIP_TRY(hipEventRecord(x->pulled[ei], cs));
-            x->pulled_valid[ei] = 1;
-        } else {
-            for (int shift = 1; shift < x->world; ++shift) {
-                const int q = (x->rank + shift) % x->world;  // start with a different peer on every rank
-                hipStream_t ps = x->streams[q];
-                H2GCN_HIP_TRY(hipStreamWaitEvent(ps, x->fence[channel], 0));
-                hipLaunchKernelGGL(wait_kernel, dim3(1), dim3(64), 0, ps, (const uint32_t*)(x->flags + channel * kMaxWorld + q),
-                                   seq, x->timeout_ticks, x->err);
-                H2GCN_HIP_TRY(hipGetLastError());
-                H2GCN_HIP_TRY(hipMemcpyAsync((char*)full + (size_t)q * bytes, x->peers.data[q] + slot_off, bytes,
-                                             hipMemcpyDeviceToDevice, ps));
-                const size_t ei = (size_t)channel * x->world + q;
-                H2GCN_HIP_TRY(hipEventRecord(x->pulled[ei], ps));
-                x->pulled_valid[ei] = 1;
-            }
-        }
-        return H2GCN_OK;
+        return issue_pulls(x, channel, seq, slot_off, bytes, (char*)full);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in xchg_allgather_begin");
     }
@@ -401,11 +426,84 @@ int h2gcn_xchg_allgather_begin(h2gcn_xchg_t* x, int channel, const float* src, i
 int h2gcn_xchg_allgather_end(h2gcn_xchg_t* x, int channel, void* stream_v) {
     if (!x) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is NULL");
     if (channel < 0 || channel >= x->n_channels) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d outside 0..%d", channel, x->n_channels - 1);
-    if (!x->open_channel[channel]) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d: end without begin", channel);
+    if (x->open_channel[channel] != 1) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d: allgather_end without its begin", channel);
     hipStream_t stream = (hipStream_t)stream_v;
     for (int q = 0; q < x->world; ++q)
         if (x->pulled_valid[(size_t)channel * x->world + q])
             H2GCN_HIP_TRY(hipStreamWaitEvent(stream, x->pulled[(size_t)channel * x->world + q], 0));
+    x->open_channel[channel] = 0;
+    return H2GCN_OK;
+}
+
+int h2gcn_xchg_reduce_scatter_begin(h2gcn_xchg_t* x, int channel, const float* src, int64_t rows_per_rank, int32_t width,
+                                    float* out, void* stream_v) {
+    try {
+        if (!x) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is NULL");
+        if (!x->connected) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is not connected");
+        if (channel < 0 || channel >= x->n_channels) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d outside 0..%d", channel, x->n_channels - 1);
+        if (x->open_channel[channel]) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d: begin without a matching end", channel);
+        if (width < 1 || rows_per_rank < 0 || (!src && rows_per_rank > 0) || !out)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad reduce-scatter operands (rows per rank %lld, width %d)", (long long)rows_per_rank, width);
+        const size_t block = (size_t)rows_per_rank * (size_t)width * 4;
+        const size_t bytes = block * (size_t)x->world;
+        if (bytes > x->slot_bytes) return fail(H2GCN_ERR_INVALID_ARGUMENT, "matrix of %zu bytes exceeds the slot (%zu)", bytes, x->slot_bytes);
+        int cur = -1;
+        H2GCN_HIP_TRY(hipGetDevice(&cur));
+        if (cur != x->device) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange lives on device %d, current device is %d", x->device, cur);
+        hipStream_t stream = (hipStream_t)stream_v;
+        if (x->rs_recv_bytes[channel] < bytes) {  // receive buffer of this channel (first use / growth)
+            if (x->rs_recv[channel]) {
+                H2GCN_HIP_TRY(hipDeviceSynchronize());
+                (void)hipFree(x->rs_recv[channel]);
+                x->rs_recv[channel] = nullptr;
+                x->rs_recv_bytes[channel] = 0;
+            }
+            H2GCN_HIP_TRY(hipMalloc((void**)&x->rs_recv[channel], bytes ? bytes : 16));
+            x->rs_recv_bytes[channel] = bytes;
+        }
+        const uint32_t seq = ++x->seq[channel];
+        const size_t slot_off = ((size_t)channel * 2 + (seq & 1u)) * x->slot_bytes;
+        H2GCN_HIP_TRY(hipEventRecord(x->fence[channel], stream));
+        for (int q = 0; q < x->world; ++q)
+            if (x->pulled_valid[(size_t)channel * x->world + q])
+                H2GCN_HIP_TRY(hipStreamWaitEvent(stream, x->pulled[(size_t)channel * x->world + q], 0));
+        if (bytes > 0) H2GCN_HIP_TRY(hipMemcpyAsync(x->data + slot_off, src, bytes, hipMemcpyDeviceToDevice, stream));
+        if (x->world > 1) {
+            hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, stream, x->peers, x->world, x->rank, channel, seq);
+            H2GCN_HIP_TRY(hipGetLastError());
+        }
+        x->open_channel[channel] = 2;
+        x->rs_pending[channel] = h2gcn_xchg::RsPending{out, (const float*)(x->data + slot_off + (size_t)x->rank * block), block / 4};
+        if (x->world == 1 || block == 0) return H2GCN_OK;
+        // every peer's slot holds its whole matrix; this rank needs block `rank` of each
+        return issue_pulls(x, channel, seq, slot_off + (size_t)x->rank * block, block, (char*)x->rs_recv[channel]);
+    } catch (...) {
+        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in xchg_reduce_scatter_begin");
+    }
+}
+
+int h2gcn_xchg_reduce_scatter_end(h2gcn_xchg_t* x, int channel, void* stream_v) {
+    if (!x) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is NULL");
+    if (channel < 0 || channel >= x->n_channels) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d outside 0..%d", channel, x->n_channels - 1);
+    if (x->open_channel[channel] != 2) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d: reduce_scatter_end without its begin", channel);
+    hipStream_t stream = (hipStream_t)stream_v;
+    for (int q = 0; q < x->world; ++q)
+        if (x->pulled_valid[(size_t)channel * x->world + q])
+            H2GCN_HIP_TRY(hipStreamWaitEvent(stream, x->pulled[(size_t)channel * x->world + q], 0));
+    const h2gcn_xchg::RsPending& pd = x->rs_pending[channel];
+    if (pd.block_elems > 0) {
+        const unsigned blocks = (unsigned)std::min<size_t>((pd.block_elems + 255) / 256, 4096);
+        hipLaunchKernelGGL(sum_blocks_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)x->rs_recv[channel], pd.own, x->world,
+                           x->rank, pd.block_elems, pd.out);
+        H2GCN_HIP_TRY(hipGetLastError());
+        // the sum reads this rank's own slot: it must be finished before the slot is staged again -> it becomes part
+        // of what the next begin on this channel waits for
+        const size_t ei = (size_t)channel * x->world + x->rank;
+        if (x->mode != H2GCN_XCHG_COPY_KERNEL) {
+            H2GCN_HIP_TRY(hipEventRecord(x->pulled[ei], stream));
+            x->pulled_valid[ei] = 1;
+        }
+    }
     x->open_channel[channel] = 0;
     return H2GCN_OK;
 }

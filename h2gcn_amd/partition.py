@@ -177,6 +177,21 @@ class IpcExchange:
             stream = torch.cuda.current_stream(self.device).cuda_stream
             self._capi.check(self._capi.lib().h2gcn_xchg_allgather_end(self._handle, int(channel), self._C.c_void_p(stream)))
 
+    def reduce_scatter(self, channel: int, src_full: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
+        """Sum over ranks of ``src_full`` ([world * rows_per_rank, w] contiguous), returning this rank's row block
+        ([rows_per_rank, w]); blocks are added in ascending rank order.  The slot must cover the whole matrix."""
+        w = int(src_full.shape[1])
+        if tuple(src_full.shape) != (self.world * rows_per_rank, w) or not src_full.is_contiguous() or src_full.dtype != torch.float32:
+            raise ValueError(f"src must be a contiguous float32 [{self.world * rows_per_rank}, w] matrix")
+        out = torch.empty((rows_per_rank, w), dtype=torch.float32, device=self.device)
+        C, L = self._C, self._capi.lib()
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            self._capi.check(L.h2gcn_xchg_reduce_scatter_begin(self._handle, int(channel), C.c_void_p(src_full.data_ptr()),
+                                                               int(rows_per_rank), w, C.c_void_p(out.data_ptr()), stream))
+            self._capi.check(L.h2gcn_xchg_reduce_scatter_end(self._handle, int(channel), stream))
+        return out
+
     def check(self) -> None:
         self._capi.check(self._capi.lib().h2gcn_xchg_status(self._handle))
 
@@ -259,6 +274,9 @@ class PipelinedHopAggregation:
         if self.ipc is not None:
             self.ipc.close()
             self.ipc = None
+        if getattr(self, "ipc_rs", None) is not None:
+            self.ipc_rs.close()
+            self.ipc_rs = None
 
     def exchange_only(self) -> None:
         """The step's exchange without the SpMM (diagnostics): every chunk of the last staged shard again."""
@@ -373,7 +391,12 @@ def _reduce_scatter_dx(layer: "PipelinedHopAggregation", dx_full: torch.Tensor) 
         return dx_full
     padded = torch.zeros((layer.world * layer.per, dx_full.shape[1]), dtype=dx_full.dtype, device=dx_full.device)
     padded[: layer.n] = dx_full
-    mine = _reduce_scatter_rows(padded, layer.per, layer.rank, layer.group)
+    if getattr(layer, "ipc", None) is not None:  # the library's own exchange: pulls + a fixed-order sum, no collective library
+        if getattr(layer, "ipc_rs", None) is None:
+            layer.ipc_rs = IpcExchange(1, layer.world * layer.per * layer.d * 4, layer.device, layer.group, mode=layer.exchange[4:])
+        mine = layer.ipc_rs.reduce_scatter(0, padded, layer.per)
+    else:
+        mine = _reduce_scatter_rows(padded, layer.per, layer.rank, layer.group)
     return mine[: layer.r1 - layer.r0]
 
 

@@ -294,6 +294,17 @@ int h2gcn_xchg_allgather_begin(h2gcn_xchg_t* x, int channel, const float* src_de
                                int64_t rows_per_rank, int32_t width, float* full_dev, void* stream);
 /* Make `stream` wait (device-side, no host block) until every shard of `channel` has landed in full_dev. */
 int h2gcn_xchg_allgather_end(h2gcn_xchg_t* x, int channel, void* stream);
+/*
+ * The mirror image for the backward pass: every rank holds a full-height contribution src_dev
+ * [world * rows_per_rank, width] (contiguous) -- the shard adjoint A_k[rows_p, :]^T dY_p -- and needs the sum over
+ * ranks of ITS row block: out_dev[r, :] = sum_q src_q[rank * rows_per_rank + r, :].  Same protocol: the matrix is
+ * staged into the exported slot (slot_bytes must cover the whole matrix), announced, and every rank pulls its block
+ * out of every peer's slot; `end` sums the blocks in ascending rank order (deterministic) on `stream`.
+ * Shares the channel's sequence counter with the all-gather: every rank must issue the same sequence of calls.
+ */
+int h2gcn_xchg_reduce_scatter_begin(h2gcn_xchg_t* x, int channel, const float* src_dev, int64_t rows_per_rank,
+                                    int32_t width, float* out_dev, void* stream);
+int h2gcn_xchg_reduce_scatter_end(h2gcn_xchg_t* x, int channel, void* stream);
 /* H2GCN_OK, or H2GCN_ERR_EXCHANGE_TIMEOUT if any wait on this object has ever given up (results are then
  * undefined).  Does not synchronise: call after the streams involved have been synchronised. */
 int h2gcn_xchg_status(const h2gcn_xchg_t* x);

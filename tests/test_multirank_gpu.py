@@ -172,9 +172,22 @@ for step in range(6):                                    # slot reuse: both halv
             want = torch.arange(rq * 200, device=dev, dtype=torch.float32).view(rq, 200)[:, off:off + w] * (q + 1) + step
             ok = ok and torch.equal(got[q * per:q * per + rq], want) and bool((got[q * per + rq:(q + 1) * per] == 0).all())
         off += w
+# reduce-scatter (the backward exchange): sum over ranks of full-height matrices, this rank's block; interleaved with
+# all-gathers on the same object (they share the channel's sequence counter)
+rs = IpcExchange(2, world * per * 24 * 4, dev, mode=mode, timeout_ms=20000)
+for step in range(5):
+    src = (torch.arange(world * per * 24, device=dev, dtype=torch.float32).view(world * per, 24) % 97) * (rank + 1) + step
+    got = rs.reduce_scatter(step % 2, src, per)
+    base = (torch.arange(world * per * 24, device=dev, dtype=torch.float32).view(world * per, 24) % 97)[rank * per:(rank + 1) * per]
+    want = base * sum(q + 1 for q in range(world)) + step * world
+    ok = ok and torch.equal(got, want)
+    if step == 2:
+        full = torch.empty((world * per, 24), device=dev)
+        rs.begin(0, src[:per], full, per); rs.end(0)
+        ok = ok and torch.equal(full[rank * per:(rank + 1) * per], src[:per])
 torch.cuda.synchronize()
-xc.check()
-xc.close()
+xc.check(); rs.check()
+xc.close(); rs.close()
 dist.barrier()
 dist.destroy_process_group()
 assert ok
