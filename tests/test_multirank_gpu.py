@@ -315,3 +315,18 @@ def test_bench_survives_an_exchange_that_fails_on_one_rank(tmp_path):
     assert diag["exchange"] == "allgather" and list(diag["calibration_ms_per_step"]) == ["allgather/2"]
     assert set(diag["rejected"]) == {"ipc_engine/2", "ipc_kernel/2"}
     assert all("IPC exchange unavailable" in v or "another rank" in v for v in diag["rejected"].values()), diag["rejected"]
+
+
+def test_bench_eight_ranks_on_one_gpu(tmp_path):
+    """The target rank count (configs[4]: 8 ranks) end to end on the arxiv shape, eight processes sharing the box's GPU:
+    block bounds, 7 peers per rank in the IPC pulls, calibration agreement across 8 ranks, the checksum against one rank.
+    (Copy-engine pulls are left out: 8 x 7 spin-wait kernels time-slicing one device take minutes, see
+    profiles/r02_ipc_exchange_stress.txt.)"""
+    out = _run_bench(8, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--chunks", "2", "--no-adjoint"], tmp_path,
+                     env_extra={"H2GCN_BENCH_EXCHANGES": "allgather,ipc_kernel"})
+    assert out["n_gpus"] == 8 and out["value"] > 0
+    cal = out["config"]["diagnostics"]["calibration_ms_per_step"]
+    assert set(cal) == {"allgather/2", "ipc_kernel/2"}, (cal, out["config"]["diagnostics"]["rejected"])
+    (ROOT / "gpurun_out" / "bench_shared_gpu_arxiv_n8.json").write_text(json.dumps(out))
+    one = _run_bench(1, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--chunks", "2", "--no-adjoint"], tmp_path)
+    assert one["config"]["y_checksum"] == out["config"]["y_checksum"]
