@@ -276,7 +276,9 @@ def test_bench_multi_rank_branch_runs_and_matches_one_rank(tmp_path, world):
     """bench.py's N > 1 branch end to end (calibration over every exchange x chunking, diagnostics, timed steps,
     JSON line) on the arxiv shape, N ranks sharing the box's GPU; the N-rank result has the same bits as the 1-rank
     result with the same chunking (order-independent checksum of Y)."""
-    out = _run_bench(world, ["--shape", "arxiv", "--steps", "3", "--warmup", "1"], tmp_path)
+    # (N = 4: the gloo stand-in for the grouped send/recv exchange takes ~3 s per step on a shared GPU -- left to N = 2)
+    extra_env = {"H2GCN_BENCH_EXCHANGES": "allgather,ipc_engine,ipc_kernel"} if world == 4 else None
+    out = _run_bench(world, ["--shape", "arxiv", "--steps", "3", "--warmup", "1"], tmp_path, env_extra=extra_env)
     assert out["n_gpus"] == world and out["value"] > 0 and out["roofline"]["kernel_ms_max_over_ranks"] > 0
     diag = out["config"]["diagnostics"]
     cal = diag["calibration_ms_per_step"]
