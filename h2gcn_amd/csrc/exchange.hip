@@ -372,8 +372,8 @@ int h2gcn_xchg_connect(h2gcn_xchg_t* x, const void* blobs) {
     }
 }
 
-int h2gcn_xchg_allgather_begin(h2gcn_xchg_t* x, int channel, const float* src, int64_t ld_src, int64_t rows,
-                               int64_t rows_per_rank, int32_t width, float* full, void* stream_v) {
+static int allgather_impl(h2gcn_xchg_t* x, int channel, const float* src, int64_t ld_src, int64_t rows,
+                          int64_t rows_per_rank, int32_t width, float* full, void* stream_v, bool do_post, bool do_pull) {
     try {
         if (!x) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is NULL");
         if (!x->connected) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is not connected");
@@ -388,6 +388,10 @@ int h2gcn_xchg_allgather_begin(h2gcn_xchg_t* x, int channel, const float* src, i
         H2GCN_HIP_TRY(hipGetDevice(&cur));
         if (cur != x->device) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange lives on device %d, current device is %d", x->device, cur);
         hipStream_t stream = (hipStream_t)stream_v;
+        if (!do_post) {  // second half of a split begin: the pulls of what allgather_post staged and announced
+            if (x->world == 1 || bytes == 0) return H2GCN_OK;
+            return issue_pulls(x, channel, x->seq[channel], ((size_t)channel * 2 + (x->seq[channel] & 1u)) * x->slot_bytes, bytes, (char*)full);
+        }
         const uint32_t seq = ++x->seq[channel];
         const size_t slot_off = ((size_t)channel * 2 + (seq & 1u)) * x->slot_bytes;
         float* own = full + (size_t)x->rank * (size_t)rows_per_rank * width;
@@ -414,13 +418,33 @@ int h2gcn_xchg_allgather_begin(h2gcn_xchg_t* x, int channel, const float* src, i
             hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, stream, x->peers, x->world, x->rank, channel, seq);
             H2GCN_HIP_TRY(hipGetLastError());
         }
-        x->open_channel[channel] = 1;
-        if (x->world == 1 || bytes == 0) return H2GCN_OK;
+        x->open_channel[channel] = do_pull ? 1 : 3;  // 3 = posted, pulls not issued yet
+        if (x->world == 1 || bytes == 0 || !do_pull) return H2GCN_OK;
 
         return issue_pulls(x, channel, seq, slot_off, bytes, (char*)full);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in xchg_allgather_begin");
     }
+}
+
+int h2gcn_xchg_allgather_begin(h2gcn_xchg_t* x, int channel, const float* src, int64_t ld_src, int64_t rows,
+                               int64_t rows_per_rank, int32_t width, float* full, void* stream) {
+    return allgather_impl(x, channel, src, ld_src, rows, rows_per_rank, width, full, stream, true, true);
+}
+
+int h2gcn_xchg_allgather_post(h2gcn_xchg_t* x, int channel, const float* src, int64_t ld_src, int64_t rows,
+                              int64_t rows_per_rank, int32_t width, float* full, void* stream) {
+    return allgather_impl(x, channel, src, ld_src, rows, rows_per_rank, width, full, stream, true, false);
+}
+
+int h2gcn_xchg_allgather_pull(h2gcn_xchg_t* x, int channel, int64_t rows_per_rank, int32_t width, float* full) {
+    if (!x) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is NULL");
+    if (channel < 0 || channel >= x->n_channels) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d outside 0..%d", channel, x->n_channels - 1);
+    if (x->open_channel[channel] != 3) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d: allgather_pull without allgather_post", channel);
+    x->open_channel[channel] = 0;  // allgather_impl re-checks "not open"
+    const int st = allgather_impl(x, channel, nullptr, width, 0, rows_per_rank, width, full, nullptr, false, true);
+    x->open_channel[channel] = 1;
+    return st;
 }
 
 int h2gcn_xchg_allgather_end(h2gcn_xchg_t* x, int channel, void* stream_v) {

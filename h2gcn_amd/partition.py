@@ -157,9 +157,10 @@ class IpcExchange:
             self._capi.lib().h2gcn_xchg_destroy(h)
             self._handle = self._C.c_void_p()
 
-    def begin(self, channel: int, x_shard: torch.Tensor, full: torch.Tensor, rows_per_rank: int) -> None:
+    def begin(self, channel: int, x_shard: torch.Tensor, full: torch.Tensor, rows_per_rank: int, pull: bool = True) -> None:
         """Start gathering ``x_shard`` ([rows <= rows_per_rank, w], last dim contiguous) into ``full``
-        ([world * rows_per_rank, w] contiguous)."""
+        ([world * rows_per_rank, w] contiguous).  ``pull=False``: only stage and announce (``h2gcn_xchg_allgather_post``);
+        call :meth:`pull` afterwards -- pipelines post every channel before pulling any."""
         if x_shard.dim() != 2 or x_shard.dtype != torch.float32 or (x_shard.shape[1] > 1 and x_shard.stride(1) != 1):
             raise ValueError("shard must be a float32 [rows, w] view with a contiguous last dimension")
         w = int(x_shard.shape[1])
@@ -168,9 +169,15 @@ class IpcExchange:
         C = self._C
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            self._capi.check(self._capi.lib().h2gcn_xchg_allgather_begin(
+            fn = self._capi.lib().h2gcn_xchg_allgather_begin if pull else self._capi.lib().h2gcn_xchg_allgather_post
+            self._capi.check(fn(
                 self._handle, int(channel), C.c_void_p(x_shard.data_ptr()), x_shard.stride(0) if x_shard.shape[0] > 0 else w,
                 int(x_shard.shape[0]), int(rows_per_rank), w, C.c_void_p(full.data_ptr()), C.c_void_p(stream)))
+
+    def pull(self, channel: int, full: torch.Tensor, rows_per_rank: int) -> None:
+        with torch.cuda.device(self.device):
+            self._capi.check(self._capi.lib().h2gcn_xchg_allgather_pull(self._handle, int(channel), int(rows_per_rank),
+                                                                        int(full.shape[1]), self._C.c_void_p(full.data_ptr())))
 
     def end(self, channel: int) -> None:
         with torch.cuda.device(self.device):
@@ -284,7 +291,9 @@ class PipelinedHopAggregation:
             return
         if self.ipc is not None:
             for c in range(self.C):
-                self.ipc.begin(c, self.send[c], self.full[c], self.per)
+                self.ipc.begin(c, self.send[c], self.full[c], self.per, pull=False)
+            for c in range(self.C):
+                self.ipc.pull(c, self.full[c], self.per)
             for c in range(self.C):
                 self.ipc.end(c)
         else:
@@ -325,7 +334,9 @@ class PipelinedHopAggregation:
             # staging + notification of every chunk first (device-side order matters, see exchange.hip), pulls run on
             # the library's own streams; the SpMM of chunk c only waits for chunk c's shards
             for c in range(self.C):
-                self.ipc.begin(c, x_local[:, cols[c]], self.full[c], self.per)
+                self.ipc.begin(c, x_local[:, cols[c]], self.full[c], self.per, pull=False)
+            for c in range(self.C):
+                self.ipc.pull(c, self.full[c], self.per)
             for c in range(self.C):
                 self.ipc.end(c)
                 self._spmm(self.full[c][: self.n], out[:, :, cols[c]], hops)

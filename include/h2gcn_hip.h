@@ -292,6 +292,13 @@ int h2gcn_xchg_connect(h2gcn_xchg_t* x, const void* blobs);
  * Returns immediately.  Exactly one allgather_end must follow before the next begin on the same channel. */
 int h2gcn_xchg_allgather_begin(h2gcn_xchg_t* x, int channel, const float* src_dev, int64_t ld_src, int64_t rows,
                                int64_t rows_per_rank, int32_t width, float* full_dev, void* stream);
+/* The same in two halves, for pipelines over several channels: `post` stages and announces (ordered on `stream`),
+ * `pull` issues the pulls (same rows_per_rank / width / full_dev).  Posting ALL channels before pulling any keeps a
+ * later channel's announcement from queueing behind an earlier channel's wait when streams share a hardware queue.
+ * begin == post immediately followed by pull. */
+int h2gcn_xchg_allgather_post(h2gcn_xchg_t* x, int channel, const float* src_dev, int64_t ld_src, int64_t rows,
+                              int64_t rows_per_rank, int32_t width, float* full_dev, void* stream);
+int h2gcn_xchg_allgather_pull(h2gcn_xchg_t* x, int channel, int64_t rows_per_rank, int32_t width, float* full_dev);
 /* Make `stream` wait (device-side, no host block) until every shard of `channel` has landed in full_dev. */
 int h2gcn_xchg_allgather_end(h2gcn_xchg_t* x, int channel, void* stream);
 /*
