@@ -221,6 +221,10 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit(f"--gpus {a.gpus} needs a torch.distributed.run launch with {a.gpus} ranks")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {a.gpus}")
+    if world > 1:
+        # the exchange pipeline drives up to world + 1 streams (main, exchange / one per peer); HIP multiplexes streams
+        # onto GPU_MAX_HW_QUEUES hardware queues (default 4) -- give every stream its own, before the runtime starts
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(world + 2, 4), 12)))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: h2gcn_amd has no CPU fallback")
     if os.environ.get("H2GCN_SHARE_GPU") == "1":  # test mode: several ranks on one GPU (RCCL refuses that -> gloo)
