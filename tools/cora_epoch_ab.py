@@ -1,0 +1,33 @@
+"""Cora epoch time of build/ab/old (an older source tree exported with `git archive`) vs the working tree through the
+CLI -- separate processes, clean sys.path.  Per-epoch time = (t(3000 epochs) - t(1000 epochs)) / 2000, so interpreter
+start-up, operand construction and hipGraph capture cancel.  Usage: python tools/cora_epoch_ab.py"""
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tests"))
+from conftest import load_planetoid_golden  # noqa: E402
+from test_entrypoints import _export_fixture  # noqa: E402
+
+data = Path(tempfile.mkdtemp())
+_export_fixture(load_planetoid_golden("cora"), data, "ind.cora")
+
+
+def wall(tree, epochs, extra):
+    t = time.perf_counter()
+    subprocess.run([sys.executable, "-m", "h2gcn_amd.run_experiments", "H2GCN", "planetoid", "--dataset", "ind.cora",
+                    "--dataset_path", str(data), "--epochs", str(epochs)] + extra, cwd=tree, check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return time.perf_counter() - t
+
+
+for rnd in (1, 2):
+    for tree in (ROOT / "build" / "ab" / "old", ROOT):
+        if not (tree / "h2gcn_amd").exists():
+            continue
+        for extra in ([], ["--no_hipgraph"]):
+            a, b = wall(tree, 1000, extra), wall(tree, 3000, extra)
+            print(f"round {rnd} tree={tree.name:5s} {' '.join(extra) or 'hipGraph replay':16s}: {(b - a) / 2000 * 1e3:.3f} ms/epoch", flush=True)
