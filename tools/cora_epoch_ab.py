@@ -1,5 +1,5 @@
 """Cora epoch time of build/ab/old (an older source tree exported with `git archive`) vs the working tree through the
-CLI -- separate processes, clean sys.path.  Per-epoch time = (t(3000 epochs) - t(1000 epochs)) / 2000, so interpreter
+CLI -- separate processes, clean sys.path.  Per-epoch time = (t(LONG epochs) - t(SHORT epochs)) / (LONG - SHORT), so interpreter
 start-up, operand construction and hipGraph capture cancel.  Usage: python tools/cora_epoch_ab.py"""
 import subprocess
 import sys
@@ -24,10 +24,11 @@ def wall(tree, epochs, extra):
     return time.perf_counter() - t
 
 
+SHORT, LONG = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1000, 3000)
 for rnd in (1, 2):
     for tree in (ROOT / "build" / "ab" / "old", ROOT):
         if not (tree / "h2gcn_amd").exists():
             continue
         for extra in ([], ["--no_hipgraph"]):
-            a, b = wall(tree, 1000, extra), wall(tree, 3000, extra)
-            print(f"round {rnd} tree={tree.name:5s} {' '.join(extra) or 'hipGraph replay':16s}: {(b - a) / 2000 * 1e3:.3f} ms/epoch", flush=True)
+            a, b = wall(tree, SHORT, extra), wall(tree, LONG, extra)
+            print(f"round {rnd} tree={tree.name:5s} {' '.join(extra) or 'hipGraph replay':16s}: {(b - a) / (LONG - SHORT) * 1e3:.3f} ms/epoch", flush=True)
