@@ -68,12 +68,13 @@ typedef struct h2gcn_plan_opts {
     int32_t long_row_threshold;  /* (row,hop) segments with >= this many nonzeros are split across the
                                     waves of one workgroup (LDS-staged partial sums); default 256          */
     int32_t rows_per_wave;       /* consecutive rows a wave walks in the regular path; default 4           */
-    int32_t variant;             /* kernel variant: 0 = default (index prefetch across segments when segments
-                                    average < 16 nonzeros); 1 = scalar-addressed float2 gathers at d=128;
-                                    2 = always prefetch; 3 = never prefetch; 4 = default, but never use the
-                                    slice-major scratch copy (A/B measurements); 5 = force the short-row mode
-                                    (one lane group per segment; default when segments average < 16 nonzeros
-                                    and the slice is 64 or 128 columns).  All variants give identical bits.    */
+    int32_t variant;             /* segment walk of the kernel: 0 = default (segments averaging >= 16 nonzeros:
+                                    one wave per segment; shorter: short-row mode -- one lane group per segment --
+                                    when the slice is 64 or 128 columns, else the wave walk with index prefetch
+                                    across segments); 1 = scalar-addressed float2 gathers at d=128; 2 = always
+                                    prefetch; 3 = plain wave walk; 4 = default, but never use the slice-major
+                                    scratch copy (A/B measurements); 5 = force the short-row mode.  Variants
+                                    0, 2, 3, 4, 5 give identical bits.                                          */
     int32_t slice_cols;          /* feature columns per slice of the slice-major schedule: 16/32/64/128/256,
                                     0 = heuristic (narrower slices when X is far beyond the Infinity Cache)  */
     int32_t reserved[2];
