@@ -468,6 +468,8 @@ def main():
         out["roofline"]["gather_ceiling_GBps"] = pr.get("gather_GBps")
         out["roofline"]["peak_achievable"] = max(pr.get("copy_GBps") or 0.0, pr.get("stream_read_GBps") or 0.0) or None
         out["roofline"]["ceilings"] = pr
+        if pr.get("gather_GBps"):
+            out["roofline"]["achieved_over_gather_ceiling"] = achieved / pr["gather_GBps"]
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(csr, x_local, d, a.cpu_seconds)
