@@ -26,5 +26,11 @@ for P in (1, 2, 4, 8):
         dc = d // C
         xb = [x[:, c * dc:(c + 1) * dc].contiguous() for c in range(C)]   # what the all-gather delivers
         res[C] = t(lambda: [plan.spmm(xb[c], out=y[:, :, c * dc:(c + 1) * dc]) for c in range(C)])
-    print(f"P={P}: rows/rank {r1 - r0}, per-rank SpMM ms by chunks {res};  ideal 1/P of 17.45 = {17.45 / P:.2f}")
+    for spec in ((32, 32, 64), (64, 32, 32)):          # the explicit chunk orders of bench.py's calibration
+        offs = [sum(spec[:i]) for i in range(len(spec))]
+        xb = [x[:, o:o + w].contiguous() for o, w in zip(offs, spec)]
+        res["+".join(map(str, spec))] = t(lambda: [plan.spmm(xb[c], out=y[:, :, offs[c]:offs[c] + spec[c]]) for c in range(len(spec))])
+    print(f"P={P}: rows/rank {r1 - r0}, per-rank SpMM ms by chunks { {k: round(v, 3) for k, v in res.items()} };  ideal 1/P of the P=1 time = {res[1] if P == 1 else base / P:.2f}")
+    if P == 1:
+        base = res[1]
     del plan, csr
