@@ -226,6 +226,42 @@ def test_scratch_copy_for_rows_that_are_not_line_aligned():
         assert np.abs(y_ws[r0:r0 + 8].cpu().numpy() - og.rows_subset(local, xs, list(range(8)))).max() <= ATOL
 
 
+def test_schedule_heuristics_are_what_the_documentation_says():
+    """h2gcn_plan_schedule: the launch-time decisions for the regimes DESIGN.md describes, queried on plans whose
+    COLUMN space and mean degree mimic the big shapes (no big operand is allocated: the decision needs sizes only)."""
+    from h2gcn_amd import HopPlan
+
+    def plan(n_rows, n_cols, deg, seed):
+        rng = np.random.default_rng(seed)
+        rows = np.repeat(np.arange(n_rows), deg)
+        cols = rng.integers(0, n_cols, n_rows * deg)
+        m = sp.csr_matrix((np.ones(len(rows), dtype=np.float32), (rows, cols)), shape=(n_rows, n_cols))
+        m.sum_duplicates()
+        m.sort_indices()
+        return HopPlan.from_scipy([m, m], dev(), build_transpose=True)
+
+    products_like = plan(2000, 2_400_000, 50, 1)          # X = 1.2 GB at d = 128, mean degree 50
+    s = products_like.schedule(128)
+    assert (s["slice_cols"], s["n_slices"], s["segment_walk"], s["scratch_copy"]) == (64, 2, "wave per segment", False)
+    assert products_like.schedule(64)["slice_cols"] == 64 and products_like.schedule(64)["n_slices"] == 1
+    s = products_like.schedule(256)                        # contiguous [N, 256]: 1 KiB stride -> slice-major scratch copy
+    assert s["scratch_copy"] is False                      # ... only when every column is gathered often enough (nnz >= 32 N)
+    dense_like = plan(160_000, 900_000, 150, 2)            # 48M nonzeros over 900k columns, X = 922 MB at d = 256
+    s = dense_like.schedule(256)
+    assert s["scratch_copy"] and s["slice_cols"] in (64, 128)
+    assert not dense_like.schedule(256, ld_src=288)["scratch_copy"]          # padded rows: no aliasing, no copy
+    assert dense_like.schedule(300)["scratch_copy"] and dense_like.schedule(300)["slice_cols"] == 64   # rows not line-aligned
+    assert not dense_like.schedule(100)["scratch_copy"] and dense_like.schedule(100)["slice_cols"] == 128
+    lowdeg_like = plan(4000, 8_000_000, 4, 3)              # mean degree 4
+    s = lowdeg_like.schedule(128)
+    assert s["segment_walk"].startswith("lane group per segment") and s["slice_cols"] == 128
+    assert lowdeg_like.schedule(128, adjoint=True)["segment_walk"] in ("wave per segment", "lane group per segment (short rows)",
+                                                                       "wave per segment + index prefetch")
+    assert lowdeg_like.schedule(32)["segment_walk"] == "wave per segment + index prefetch"          # slice 32: no short-row kernel
+    small = plan(3000, 3000, 20, 4)
+    assert small.schedule(128)["slice_cols"] == 128 and small.schedule(448)["slice_cols"] == 64 and small.schedule(448)["n_slices"] == 7
+
+
 @pytest.mark.parametrize("d", [64, 100, 7])
 def test_fused_bias_relu_epilogue(d):
     """Y = relu(A X + b) in one launch (SparseDense.call: bias, then activation, reference _layers.py:45-52): every
