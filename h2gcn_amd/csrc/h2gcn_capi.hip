@@ -265,6 +265,8 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
     using namespace h2gcn;
     const Schedule sc = decide(variant, vec_ok, p.d, p.rows_per_wave, p.n_sel, forced_slice, n_src_rows, avg_segment_nnz);
     const bool epi = !SUM && (p.bias != nullptr || p.relu != 0);  // bias / ReLU epilogue: dedicated instantiations
+    // short-row kernels: shallow fallback batches (more waves per SIMD) once the gather source is far beyond the caches
+    const bool short_fb4 = (double)n_src_rows * p.d * 4.0 >= 512.0 * 1024 * 1024;
     const bool pipe = sc.pipe && !epi, scalar128 = sc.scalar128, exact = sc.exact, shortrow = sc.shortrow && !epi;
     const int slice = sc.slice;
     p.slice_cols = exact ? (slice > 0 ? slice : 128) : p.d;
@@ -275,12 +277,16 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
     if (n_blocks <= 0) return H2GCN_OK;
     if (n_blocks > 0x7fffffffLL) return fail(H2GCN_ERR_INVALID_ARGUMENT, "grid too large (%lld blocks)", (long long)n_blocks);
     const dim3 grid((unsigned)n_blocks), block(kBlock);
-#define H2GCN_LAUNCH_SHORT(VEC, LPR)                                                                                    \
-    do {                                                                                                                \
-        if (off32)                                                                                                      \
-            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, true, false, true>), grid, block, 0, stream, p);   \
-        else                                                                                                            \
-            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, false, false, true>), grid, block, 0, stream, p);  \
+#define H2GCN_LAUNCH_SHORT(VEC, LPR)                                                                                              \
+    do {                                                                                                                          \
+        if (off32 && short_fb4)                                                                                                   \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, true, false, true, false, 4>), grid, block, 0, stream, p);   \
+        else if (off32)                                                                                                           \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, true, false, true, false, 8>), grid, block, 0, stream, p);   \
+        else if (short_fb4)                                                                                                       \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, false, false, true, false, 4>), grid, block, 0, stream, p);  \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, false, false, true, false, 8>), grid, block, 0, stream, p);  \
     } while (0)
 #define H2GCN_LAUNCH(VEC, LPR, EXACT)                                                                             \
     do {                                                                                                          \

@@ -45,7 +45,10 @@ constexpr int kMaxRowsPerWave = 7;  // (rows_per_wave + 1) * n_hops row pointers
 #ifndef H2GCN_MIN_WAVES
 #define H2GCN_MIN_WAVES 6
 #endif
-constexpr int kMinWavesPerSimd = H2GCN_MIN_WAVES;  // __launch_bounds__ of the fast paths (waves per SIMD the register budget must allow)
+constexpr int kMinWavesPerSimd = H2GCN_MIN_WAVES;
+#ifndef H2GCN_SHORT_MIN_WAVES
+#define H2GCN_SHORT_MIN_WAVES 4
+#endif  // __launch_bounds__ of the fast paths (waves per SIMD the register budget must allow)
 constexpr int kMaxTileCols = 256;   // columns one pass of a wave covers at most (64 lanes x float4)
 
 struct HopCsr {
@@ -227,13 +230,19 @@ __device__ __forceinline__ void load_chunk(const int32_t* __restrict__ colidx, c
 }
 
 // All gathers + multiply-adds of one chunk of n (<= 64) neighbours held lane-wise in (c, v).
-template <int VEC, int LPR, bool MASKED, bool OFF32>
+// MAXB: deepest load batch (8 in the bandwidth kernels; 4 where register pressure matters more than the last few
+// percent on long segments -- the fallback walk of the short-row kernels).  The batch depth only re-times loads: the
+// accumulation order, hence the bits, do not depend on it.
+template <int VEC, int LPR, bool MASKED, bool OFF32, int MAXB = 8>
 __device__ __forceinline__ void process_chunk(int c, float v, int n, int g, const GatherAddr<OFF32>& addr,
                                               bool lane_active, float (&acc)[VEC]) {
     constexpr int G = kWave / LPR;
     const int full = n / G;  // steps in which every lane group has a neighbour
     int t = 0;
-    for (; t + 8 <= full; t += 8) gather_batch<VEC, LPR, 8, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
+    if constexpr (MAXB >= 8)
+        for (; t + 8 <= full; t += 8) gather_batch<VEC, LPR, 8, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
+    if constexpr (MAXB < 8)
+        for (; t + 4 <= full; t += 4) gather_batch<VEC, LPR, 4, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
     if (t + 4 <= full) {
         gather_batch<VEC, LPR, 4, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
         t += 4;
@@ -256,7 +265,7 @@ __device__ __forceinline__ void process_chunk(int c, float v, int n, int g, cons
 // Accumulate sum_j val_j * src[col_j, :] over the nonzeros [seg_begin, seg_end) of one CSR row, taking the
 // 64-wide chunks chunk0, chunk0+chunk_step, ... (regular path: all of them; long path: this wave's share).
 // Each lane group accumulates its neighbours in ascending order into acc.
-template <int VEC, int LPR, bool MASKED, bool OFF32>
+template <int VEC, int LPR, bool MASKED, bool OFF32, int MAXB = 8>
 __device__ __forceinline__ void accumulate_segment(const int32_t* __restrict__ colidx,
                                                    const float* __restrict__ vals, int64_t seg_begin,
                                                    int64_t seg_end, int chunk0, int chunk_step,
@@ -269,7 +278,7 @@ __device__ __forceinline__ void accumulate_segment(const int32_t* __restrict__ c
         int c;
         float v;
         load_chunk(colidx, vals, base, seg_end, lane, c, v);
-        process_chunk<VEC, LPR, MASKED, OFF32>(c, v, n, g, addr, lane_active, acc);
+        process_chunk<VEC, LPR, MASKED, OFF32, MAXB>(c, v, n, g, addr, lane_active, acc);
     }
 }
 
@@ -384,8 +393,11 @@ __device__ __forceinline__ void store_vec(float* p, const float (&acc)[VEC]) {
 //        lane group per segment; other rounds fall back to the wave-per-segment walk.  Same bits either way.
 // EPI    the store applies the optional bias / ReLU epilogue (separate instantiations: the epilogue's registers would
 //        otherwise push the 6-waves-per-SIMD variants of the plain aggregation into spilling)
-template <int VEC, int LPR, bool EXACT, bool SUM, bool OFF32, bool PIPE = false, bool SHORT = false, bool EPI = false>
-__global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? 4 : kMinWavesPerSimd) : 2) void spmm_hops_kernel(const LaunchParams p) {
+// FB     (short-row kernels) deepest load batch of the wave-per-segment fallback: 4 keeps the kernel at 7 waves per SIMD
+//        (memory-resident operands: occupancy buys bandwidth), 8 at 5 (cache-resident operands: the longer segments'
+//        loads in flight matter more)
+template <int VEC, int LPR, bool EXACT, bool SUM, bool OFF32, bool PIPE = false, bool SHORT = false, bool EPI = false, int FB = 8>
+__global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kMinWavesPerSimd) : 2) void spmm_hops_kernel(const LaunchParams p) {
     static_assert(EXACT || LPR == kWave, "column-tiled path uses the whole wave per row");
     __shared__ float partial[kWavesPerBlock][kMaxTileCols];
     using off_t = typename std::conditional<OFF32, uint32_t, int64_t>::type;
@@ -496,7 +508,7 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? 4 : kMinWavesPerSimd) : 2)
                 const HopCsr& h = p.hop[s];
                 GatherAddr<OFF32> addr = addr0;
                 addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin);
-                accumulate_segment<VEC, LPR, false, OFF32>(h.colidx, h.vals, sb, se, 0, 1, addr, lane, true, acc);
+                accumulate_segment<VEC, LPR, false, OFF32, FB>(h.colidx, h.vals, sb, se, 0, 1, addr, lane, true, acc);
                 if constexpr (!SUM) {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
