@@ -233,7 +233,10 @@ __device__ __forceinline__ void load_chunk(const int32_t* __restrict__ colidx, c
 // MAXB: deepest load batch (8 in the bandwidth kernels; 4 where register pressure matters more than the last few
 // percent on long segments -- the fallback walk of the short-row kernels).  The batch depth only re-times loads: the
 // accumulation order, hence the bits, do not depend on it.
-template <int VEC, int LPR, bool MASKED, bool OFF32, int MAXB = 8>
+#ifndef H2GCN_MAIN_MAXB
+#define H2GCN_MAIN_MAXB 8
+#endif
+template <int VEC, int LPR, bool MASKED, bool OFF32, int MAXB = H2GCN_MAIN_MAXB>
 __device__ __forceinline__ void process_chunk(int c, float v, int n, int g, const GatherAddr<OFF32>& addr,
                                               bool lane_active, float (&acc)[VEC]) {
     constexpr int G = kWave / LPR;
@@ -265,7 +268,7 @@ __device__ __forceinline__ void process_chunk(int c, float v, int n, int g, cons
 // Accumulate sum_j val_j * src[col_j, :] over the nonzeros [seg_begin, seg_end) of one CSR row, taking the
 // 64-wide chunks chunk0, chunk0+chunk_step, ... (regular path: all of them; long path: this wave's share).
 // Each lane group accumulates its neighbours in ascending order into acc.
-template <int VEC, int LPR, bool MASKED, bool OFF32, int MAXB = 8>
+template <int VEC, int LPR, bool MASKED, bool OFF32, int MAXB = H2GCN_MAIN_MAXB>
 __device__ __forceinline__ void accumulate_segment(const int32_t* __restrict__ colidx,
                                                    const float* __restrict__ vals, int64_t seg_begin,
                                                    int64_t seg_end, int chunk0, int chunk_step,
