@@ -14,7 +14,7 @@ from pathlib import Path
 
 import pandas as pd
 
-KERNEL = re.compile(r"spmm_hops_kernel<(\d+), (\d+), (true|false), (true|false), (true|false), (true|false)(?:, (?:true|false))*>")  # VEC, LPR, EXACT, SUM, OFF32, PIPE[, SHORT, EPI]
+KERNEL = re.compile(r"spmm_hops_kernel<(\d+), (\d+), (true|false), (true|false), (true|false), (true|false)(?:, (?:true|false|\d+))*>")  # VEC, LPR, EXACT, SUM, OFF32, PIPE[, SHORT, EPI]
 PEAK = 8000.0
 
 
