@@ -302,14 +302,14 @@ def main():
     else:
         exchanges = [a.exchange] if a.exchange else os.environ.get(
             "H2GCN_BENCH_EXCHANGES", "allgather,p2p,ipc_engine,ipc_kernel").split(",")
-        # "32+32+64": short exposed head when the step is compute-bound; "64+32+32": short exposed tail (the last SpMM) when it
-        # is exchange-bound -- which of the two regimes a node is in is exactly what is being measured
-        chunk_specs = [a.chunks] if a.chunks else ["1", "2", "4", "32+32+64", "64+32+32"]
+        # chunks stay >= 64 columns: every such width builds the canonical summation tree, so the checksum of Y is the
+        # same for every candidate and equal to the 1-GPU line's (narrower chunks would also cost +6-12 % SpMM time)
+        chunk_specs = [a.chunks] if a.chunks else ["1", "2", "4"]
         cands = {}
         for ex in exchanges:
             for spec in chunk_specs:
                 widths = parse_chunks(spec, d)
-                if isinstance(widths, int) and (d % widths or d // widths < 32):
+                if isinstance(widths, int) and (d % widths or (widths > 1 and d // widths < 64)):
                     continue
                 if isinstance(widths, list) and sum(widths) != d:
                     continue

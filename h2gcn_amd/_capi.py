@@ -11,7 +11,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_HOPS = 8
 
 OK = 0
@@ -46,6 +46,7 @@ EXPORTED_SYMBOLS = (
     "h2gcn_plan_schedule",
     "h2gcn_spmm_workspace_bytes",
     "h2gcn_spmm_hops_opts_f32",
+    "h2gcn_spmm_hops_T_opts_f32",
     "h2gcn_ring_scratch_bytes",
     "h2gcn_ring_count",
     "h2gcn_ring_fill",
@@ -151,10 +152,15 @@ def lib() -> C.CDLL:
     L.h2gcn_plan_schedule.restype = C.c_int
     L.h2gcn_plan_schedule.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int64, C.c_int32] + [C.POINTER(C.c_int32)] * 4
     L.h2gcn_spmm_workspace_bytes.restype = C.c_size_t
-    L.h2gcn_spmm_workspace_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_int32]
+    L.h2gcn_spmm_workspace_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int32]
     L.h2gcn_spmm_hops_opts_f32.restype = C.c_int
     L.h2gcn_spmm_hops_opts_f32.argtypes = [
         C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64,
+        C.POINTER(LaunchOpts), C.c_void_p,
+    ]
+    L.h2gcn_spmm_hops_T_opts_f32.restype = C.c_int
+    L.h2gcn_spmm_hops_T_opts_f32.argtypes = [
+        C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
         C.POINTER(LaunchOpts), C.c_void_p,
     ]
     L.h2gcn_ring_scratch_bytes.restype = C.c_size_t

@@ -179,59 +179,89 @@ int get_long_list(const h2gcn_plan* plan, bool adjoint, uint32_t mask, const int
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Column-slice width of the EXACT kernels (requires d % 4 == 0 and 16-byte aligned operands; n_slices =
+// Column-slice width of the EXACT kernels (float4 lanes: 16-byte addressable source with d_src % 4 == 0; n_slices =
 // ceil(d / slice), a partial last slice is masked in the kernel).
-//   * d a multiple of 16: the largest fast width that divides d, capped so that the gather working set of one slice
+//   * d >= 64: only the widths whose lane geometry yields the canonical summation tree (64 / 128 / 256 columns, see
+//     spmm_kernels.hip.h) -- the largest one that divides d, capped so that the gather working set of one slice
 //     (n_src_rows * slice * 4 B) is friendlier to the 256 MiB Infinity Cache when the whole operand is far beyond it;
-//   * other d (e.g. --hidden 100 -> d = 100, 200): one masked slice of the next power of two up to 256 columns, and
-//     slices of 128 beyond that (the last one masked).
-// `forced` > 0 (plan option) overrides the heuristic.
+//     widths none of them divides (d = 96, 100, 200 ...): one masked slice of the next power of two up to 256 columns,
+//     slices of 128 beyond that (the last one masked);
+//   * d < 64: narrow slices of 32 / 16 columns (8 / 16 gathered rows per load instruction; their own, wider tree --
+//     no feature chunking ever goes below 64 columns, so this is not observable across partitions).
+// `forced` > 0 (plan option / scratch layout) overrides the heuristic.
 int pick_slice_cols(int d, int64_t n_src_rows, int forced, double avg_segment_nnz) {
-    static const int widths[] = {256, 128, 64, 32, 16};
     if (forced > 0) return forced;
-    if (d % 16 != 0) {
-        if (d > 256) return 128;
+    if (d < 64) {
+        if (d % 32 == 0) return 32;
+        if (d % 16 == 0) return 16;
         int w = 16;
         while (w < d) w *= 2;
         return w;
     }
-    int best = 0;
+    static const int widths[] = {256, 128, 64};
     for (int w : widths) {
         if (d % w != 0) continue;
-        if (best == 0) best = w;
         const double slice_bytes = (double)n_src_rows * w * 4.0;
         // narrower slices pay one more pass over the row pointers / indices and one more latency chain per
         // segment: only worth it when segments are long enough to amortise that, and never below 64 columns
         if (w > 64 && avg_segment_nnz >= 16.0 && slice_bytes > 768.0 * 1024 * 1024 && d % (w / 2) == 0) continue;
         return w;
     }
-    return best;
+    if (d > 256) return 128;
+    int w = 64;
+    while (w < d) w *= 2;
+    return w;
 }
 
-// Forward launches whose X has a row stride that is a multiple of 1 KiB gather faster from a slice-major scratch
-// copy (see repack_slice_major_kernel).  Worth it when the operand is far beyond the caches and every row of X is
-// gathered often enough to amortise the copy (2 * n_cols * d * 4 bytes against nnz * d * 4 gathered bytes).
-// Returns the slice width of the scratch layout, 0 = do not repack.
-int repack_slice_cols(const h2gcn_plan* plan, int64_t nnz_sel, int n_sel, int64_t ldx, int d) {
-    if (plan->variant == 4) return 0;                       // variant 4: never repack (A/B measurements)
-    if (d % 4 != 0 || d <= 64) return 0;
-    if ((double)plan->n_cols * d * 4.0 < 512.0 * 1024 * 1024) return 0;   // operand must be far beyond the caches
-    if ((double)nnz_sel < 32.0 * (double)plan->n_cols) return 0;          // ... and gathered often enough
-    const double avg = (double)nnz_sel / ((double)plan->n_rows * n_sel);
-    if ((ldx * 4) % 1024 == 0 && d % 64 == 0 && d >= 128) {
-        // power-of-two-ish stride: the slice width the plain launch would use (same width => same summation tree =>
-        // bit-identical results)
-        const int w = pick_slice_cols(d, plan->n_cols, plan->slice_cols, avg);
+// What the schedule of one launch depends on.
+struct LaunchShape {
+    bool adjoint;
+    int n_sel;
+    int64_t nnz_sel;
+    int64_t n_out, n_src;   // output rows / rows of the gather source
+    double avg;             // nonzeros per (row, hop) segment
+    bool src_vec_ok;        // gather source 16-byte addressable: base pointer, row stride, hop offsets
+    int64_t ld_src;
+    int d;
+};
+
+// Slice width of the slice-major scratch copy this launch should gather from (see repack_slice_major_kernel);
+// 0 = gather from the source as it is.  Because every slice width >= 64 produces the same summation tree, the copy
+// never changes a bit of the result.
+int scratch_slice_cols(const h2gcn_plan* plan, const LaunchShape& sh) {
+    if (plan->variant == 4) return 0;  // variant 4: never repack (A/B measurements)
+    const int d = sh.d;
+    if (sh.n_out == 0 || sh.n_src == 0 || sh.n_sel == 0) return 0;
+    if (!sh.src_vec_ok || d % 4 != 0) {
+        // odd widths / unaligned sources: zero-padded 16-byte addressable blocks, so that the float4 gather kernels
+        // serve them instead of the column-tiled kernel (up to 32 columns that kernel is the better tool: one pass of
+        // 64 lanes covers the row, and a 64-column padded copy would multiply the gathered bytes)
+        if (d <= 32) return 0;
+        const int f = plan->slice_cols;
+        return (f == 64 || f == 128 || f == 256) ? f : 64;
+    }
+    if (d <= 64) return 0;
+    const double src_bytes = (double)sh.n_src * d * 4.0 * (sh.adjoint ? sh.n_sel : 1);
+    if (src_bytes < 512.0 * 1024 * 1024) return 0;                  // operand must be far beyond the caches
+    if ((double)sh.nnz_sel < 32.0 * (double)sh.n_src) return 0;     // ... and gathered often enough to amortise the copy
+    if (!sh.adjoint && (sh.ld_src * 4) % 1024 == 0 && d % 64 == 0 && d >= 128) {
+        // power-of-two-ish stride: the slice width the plain launch would use
+        const int w = pick_slice_cols(d, sh.n_src, plan->slice_cols, sh.avg);
         return (w == 64 || w == 128) && d % w == 0 && w < d ? w : 0;
     }
-    if ((ldx * 4) % 128 != 0 && d > 128 && avg >= 16.0 && (plan->slice_cols == 0 || plan->slice_cols == 64)) {
+    if ((sh.ld_src * 4) % 128 != 0 && d > 128 && sh.avg >= 16.0 && (plan->slice_cols == 0 || plan->slice_cols == 64)) {
         // rows that are not cache-line aligned and wider than one 128-column slice: line-aligned, cache-sized 64-column
         // blocks (d = 132: +5 %, 200: +3 %, 300: +30 % including the copy; d = 100 gains nothing: two blocks fetch the
-        // same 512 B per edge as the unaligned row and pay a second index pass).  Results agree with the plain launch
-        // to rounding, not bitwise: the slice width differs.
+        // same 512 B per edge as the unaligned row and pay a second index pass)
         return 64;
     }
     return 0;
+}
+
+size_t scratch_bytes(const LaunchShape& sh, int rs) {
+    if (rs <= 0) return 0;
+    const size_t n_slices = (size_t)((sh.d + rs - 1) / rs);
+    return (size_t)sh.n_src * n_slices * (size_t)rs * 4 * (size_t)(sh.adjoint ? sh.n_sel : 1);
 }
 
 struct Schedule {
@@ -239,17 +269,17 @@ struct Schedule {
     int slice;
 };
 
-// The launch-time decisions (also reported by h2gcn_plan_schedule).
-Schedule decide(int variant, bool vec_ok, int d, int rows_per_wave, int n_sel, int forced_slice, int64_t n_src_rows,
+// The launch-time decisions (also reported by h2gcn_plan_schedule).  `exact_ok`: the float4 kernels can read the
+// source (16-byte addressable, valid width a multiple of 4).
+Schedule decide(int variant, bool exact_ok, int d, int rows_per_wave, int n_sel, int forced_slice, int64_t n_src_rows,
                 double avg_segment_nnz) {
     Schedule sc;
     // index prefetch across segments: pays on short segments (+4 % at mean degree 4), costs ~0.4 % on long ones;
     // variant 2 forces it, variant 3 forbids it (bitwise-identical results either way)
     if (variant == 4) variant = 0;
     sc.pipe = (variant == 2 || (variant == 0 && avg_segment_nnz < 16.0)) && rows_per_wave * n_sel <= 32;
-    sc.scalar128 = vec_ok && variant == 1 && d == 128;  // variant 1 only exists for d = 128
-    const bool sliced_ok = vec_ok && d % 4 == 0;        // float4 lanes; a partial last slice is masked
-    sc.slice = (sliced_ok && !sc.scalar128) ? pick_slice_cols(d, n_src_rows, forced_slice, avg_segment_nnz) : 0;
+    sc.scalar128 = exact_ok && variant == 1 && d == 128 && forced_slice == 0;  // variant 1 only exists for d = 128
+    sc.slice = (exact_ok && !sc.scalar128) ? pick_slice_cols(d, n_src_rows, forced_slice, avg_segment_nnz) : 0;
     sc.exact = sc.slice > 0 || sc.scalar128;
     // short segments: one lane group per segment (G segments of a wave in flight at once) -- slices of 64 / 128 columns;
     // variant 5 forces it, variants 2 / 3 keep the wave-per-segment walk with / without the index prefetch
@@ -260,14 +290,17 @@ Schedule decide(int variant, bool vec_ok, int d, int rows_per_wave, int n_sel, i
 }
 
 template <bool SUM>
-int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_slice, int64_t n_src_rows,
-           double avg_segment_nnz, hipStream_t stream) {
+int launch(LaunchParams& p, int variant, bool src_vec_ok, bool dst_vec_ok, bool off32, int forced_slice,
+           int64_t n_src_rows, double avg_segment_nnz, hipStream_t stream) {
     using namespace h2gcn;
-    const Schedule sc = decide(variant, vec_ok, p.d, p.rows_per_wave, p.n_sel, forced_slice, n_src_rows, avg_segment_nnz);
-    const bool epi = !SUM && (p.bias != nullptr || p.relu != 0);  // bias / ReLU epilogue: dedicated instantiations
+    const bool exact_ok = src_vec_ok && p.d_src % 4 == 0;
+    const Schedule sc = decide(variant, exact_ok, p.d, p.rows_per_wave, p.n_sel, forced_slice, n_src_rows, avg_segment_nnz);
+    p.dst_scalar = (!dst_vec_ok || p.d % 4 != 0) ? 1 : 0;
+    // general store (bias / ReLU epilogue, element-wise bounded stores): dedicated instantiations
+    const bool gen = p.dst_scalar || p.bias != nullptr || p.relu != 0;
     // short-row kernels: shallow fallback batches (more waves per SIMD) once the gather source is far beyond the caches
     const bool short_fb4 = (double)n_src_rows * p.d * 4.0 >= 512.0 * 1024 * 1024;
-    const bool pipe = sc.pipe && !epi, scalar128 = sc.scalar128, exact = sc.exact, shortrow = sc.shortrow && !epi;
+    const bool pipe = sc.pipe && !gen, scalar128 = sc.scalar128, exact = sc.exact, shortrow = sc.shortrow && !gen;
     const int slice = sc.slice;
     p.slice_cols = exact ? (slice > 0 ? slice : 128) : p.d;
     p.n_slices = exact ? (p.d + p.slice_cols - 1) / p.slice_cols : 1;
@@ -290,10 +323,10 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
     } while (0)
 #define H2GCN_LAUNCH(VEC, LPR, EXACT)                                                                             \
     do {                                                                                                          \
-        if (epi && off32)                                                                                         \
-            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, true, false, false, !SUM>), grid, block, 0, stream, p);  \
-        else if (epi)                                                                                             \
-            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, false, false, false, !SUM>), grid, block, 0, stream, p); \
+        if (gen && off32)                                                                                         \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, true, false, false, true>), grid, block, 0, stream, p);  \
+        else if (gen)                                                                                             \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, false, false, false, true>), grid, block, 0, stream, p); \
         else if (off32 && pipe && EXACT)                                                                               \
             hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, EXACT, SUM, true, true>), grid, block, 0, stream, p);   \
         else if (off32)                                                                                           \
@@ -318,14 +351,36 @@ int launch(LaunchParams& p, int variant, bool vec_ok, bool off32, int forced_sli
     } else if (slice == 32) {
         H2GCN_LAUNCH(4, 8, true);
     } else if (slice == 16) {
-        H2GCN_LAUNCH(4, 4, true);  // 64-byte rows, 16 neighbours per load instruction (narrow exchange chunks)
+        H2GCN_LAUNCH(4, 4, true);  // 64-byte rows, 16 neighbours per load instruction
     } else {
-        H2GCN_LAUNCH(1, 64, false);  // d % 4 != 0 or unaligned operands: scalar column-tiled path
+        H2GCN_LAUNCH(1, 64, false);  // no scratch and (d % 4 != 0 or unaligned source): generic column-tiled path
     }
 #undef H2GCN_LAUNCH
 #undef H2GCN_LAUNCH_SHORT
     H2GCN_HIP_TRY(hipGetLastError());
     return H2GCN_OK;
+}
+
+// Copy the gather source into the slice-major scratch and point the launch at it.
+void use_scratch(LaunchParams& p, const LaunchShape& sh, int rs, bool src_vec_ok, int64_t ld_src_hop, void* workspace,
+                 hipStream_t stream, bool* off32) {
+    const int n_hop = sh.adjoint ? sh.n_sel : 1;
+    const int n_slices = (sh.d + rs - 1) / rs;
+    const bool vec4 = src_vec_ok && sh.d % 4 == 0;
+    const int64_t total = sh.n_src * (int64_t)n_slices * n_hop * (rs / (vec4 ? 4 : 1));
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 64);
+    if (vec4)
+        hipLaunchKernelGGL(h2gcn::repack_slice_major_kernel<true>, dim3(blocks), dim3(256), 0, stream, p.src, sh.ld_src,
+                           ld_src_hop, n_hop, sh.n_src, sh.d, n_slices, rs, (float*)workspace);
+    else
+        hipLaunchKernelGGL(h2gcn::repack_slice_major_kernel<false>, dim3(blocks), dim3(256), 0, stream, p.src, sh.ld_src,
+                           ld_src_hop, n_hop, sh.n_src, sh.d, n_slices, rs, (float*)workspace);
+    p.src = (const float*)workspace;
+    p.ld_src = rs;
+    p.d_src = (sh.d + 3) & ~3;   // lanes beyond it re-read the row's last valid float4 instead of the zero padding
+    p.src_slice_stride = sh.n_src * (int64_t)rs * n_hop;
+    for (int s = 0; s < p.n_sel; ++s) p.src_hop_off[s] = sh.adjoint ? (int64_t)s * sh.n_src * rs : 0;
+    *off32 = (double)sh.n_src * (double)n_slices * rs * n_hop * 4.0 < 4294967296.0;
 }
 
 int check_device(const h2gcn_plan* plan) {
@@ -550,44 +605,61 @@ int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t*
     return H2GCN_OK;
 }
 
+namespace {
+// hop selection -> LaunchShape (src_vec_ok / ld_src / d are filled in by the caller)
+LaunchShape shape_of(const h2gcn_plan* plan, uint32_t mask, bool adjoint) {
+    LaunchShape sh;
+    memset(&sh, 0, sizeof(sh));
+    sh.adjoint = adjoint;
+    const std::vector<HopOperand>& ops = adjoint ? plan->adj : plan->fwd;
+    for (int k = 0; k < plan->n_hops; ++k)
+        if (mask & (1u << k)) { sh.nnz_sel += ops[k].nnz; ++sh.n_sel; }
+    sh.n_out = adjoint ? plan->n_cols : plan->n_rows;
+    sh.n_src = adjoint ? plan->n_rows : plan->n_cols;
+    sh.avg = (sh.n_out > 0 && sh.n_sel > 0) ? (double)sh.nnz_sel / ((double)sh.n_out * sh.n_sel) : 0.0;
+    return sh;
+}
+
+bool source_vec_ok(const float* src, int64_t ld_src, int64_t ld_src_hop, int n_sel, bool adjoint) {
+    return aligned16(src) && ld_src % 4 == 0 && (!adjoint || n_sel <= 1 || ld_src_hop % 4 == 0);
+}
+}  // namespace
+
 int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, int64_t ld_src, int32_t d,
-                        int32_t* slice_cols, int32_t* n_slices, int32_t* index_prefetch, int32_t* scratch_copy) {
+                        int32_t* slice_cols, int32_t* n_slices, int32_t* segment_walk, int32_t* scratch_copy) {
     if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
     uint32_t mask;
     int st = resolve_mask(plan, hop_mask, &mask);
     if (st != H2GCN_OK) return st;
     if (d < 1 || ld_src < d) return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad width %d / stride %lld", d, (long long)ld_src);
     if (adjoint && !plan->has_transpose) return fail(H2GCN_ERR_NO_TRANSPOSE, "plan was created without H2GCN_PLAN_BUILD_TRANSPOSE");
-    const std::vector<HopOperand>& ops = adjoint ? plan->adj : plan->fwd;
-    int64_t nnz_sel = 0;
-    int n_sel = 0;
-    for (int k = 0; k < plan->n_hops; ++k)
-        if (mask & (1u << k)) { nnz_sel += ops[k].nnz; ++n_sel; }
-    const int64_t n_out = adjoint ? plan->n_cols : plan->n_rows, n_src = adjoint ? plan->n_rows : plan->n_cols;
-    const double avg = n_out > 0 ? (double)nnz_sel / ((double)n_out * n_sel) : 0.0;
-    const bool vec_ok = ld_src % 4 == 0;  // 16-byte aligned base pointers assumed
-    const int rs = (!adjoint && vec_ok && n_out > 0) ? repack_slice_cols(plan, nnz_sel, n_sel, ld_src, d) : 0;
-    const Schedule sc = decide(plan->variant, vec_ok, d, plan->rows_per_wave, n_sel, rs > 0 ? rs : plan->slice_cols, n_src, avg);
+    LaunchShape sh = shape_of(plan, mask, adjoint != 0);
+    sh.src_vec_ok = ld_src % 4 == 0;  // 16-byte aligned base pointers (and hop stride d) assumed
+    if (adjoint && sh.n_sel > 1 && d % 4 != 0) sh.src_vec_ok = false;
+    sh.ld_src = ld_src;
+    sh.d = d;
+    const int rs = scratch_slice_cols(plan, sh);
+    const bool exact_ok = rs > 0 || (sh.src_vec_ok && d % 4 == 0);
+    const Schedule sc = decide(plan->variant, exact_ok, d, plan->rows_per_wave, sh.n_sel, rs > 0 ? rs : plan->slice_cols, sh.n_src, sh.avg);
     const int w = sc.exact ? (sc.slice > 0 ? sc.slice : 128) : d;
     if (slice_cols) *slice_cols = w;
     if (n_slices) *n_slices = sc.exact ? (d + w - 1) / w : 1;
-    if (index_prefetch) *index_prefetch = sc.pipe ? 1 : (sc.shortrow ? 2 : 0);
+    if (segment_walk) *segment_walk = sc.pipe ? 1 : (sc.shortrow ? 2 : 0);
     if (scratch_copy) *scratch_copy = rs > 0 ? 1 : 0;
     return H2GCN_OK;
 }
 
-size_t h2gcn_spmm_workspace_bytes(const h2gcn_plan_t* plan, uint32_t hop_mask, int64_t ldx, int32_t d) {
-    if (!plan || d < 1 || ldx < d) return 0;
+size_t h2gcn_spmm_workspace_bytes(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, const float* src_dev,
+                                  int64_t ld_src, int64_t ld_src_hop, int32_t d) {
+    if (!plan || d < 1 || ld_src < d) return 0;
+    if (adjoint && !plan->has_transpose) return 0;
     uint32_t mask;
     if (resolve_mask(plan, hop_mask, &mask) != H2GCN_OK) return 0;
-    int64_t nnz_sel = 0;
-    for (int k = 0; k < plan->n_hops; ++k)
-        if (mask & (1u << k)) nnz_sel += plan->fwd[k].nnz;
-    int n_sel = 0;
-    for (int k = 0; k < plan->n_hops; ++k) n_sel += (mask >> k) & 1u;
-    if (plan->n_rows == 0 || n_sel == 0) return 0;
-    const int rs = repack_slice_cols(plan, nnz_sel, n_sel, ldx, d);
-    return rs > 0 ? (size_t)plan->n_cols * (size_t)((d + rs - 1) / rs) * (size_t)rs * 4 : 0;
+    LaunchShape sh = shape_of(plan, mask, adjoint != 0);
+    sh.src_vec_ok = source_vec_ok(src_dev, ld_src, ld_src_hop, sh.n_sel, adjoint != 0);
+    sh.ld_src = ld_src;
+    sh.d = d;
+    return scratch_bytes(sh, scratch_slice_cols(plan, sh));
 }
 
 int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X, int64_t ldx, int32_t d,
@@ -595,23 +667,29 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
     return h2gcn_spmm_hops_opts_f32(plan, hop_mask, X, ldx, d, Y, ldy_row, ldy_hop, nullptr, stream_v);
 }
 
+namespace {
+int read_launch_opts(const h2gcn_launch_opts* lopts, h2gcn_launch_opts* lo) {
+    memset(lo, 0, sizeof(*lo));
+    if (lopts) {
+        if (lopts->struct_size < 8 || lopts->struct_size > sizeof(*lo))
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "launch opts struct_size = %u", lopts->struct_size);
+        memcpy(lo, lopts, lopts->struct_size);
+    }
+    if (lo->flags & ~(uint32_t)H2GCN_LAUNCH_RELU) return fail(H2GCN_ERR_INVALID_ARGUMENT, "unknown launch flags 0x%x", lo->flags);
+    return H2GCN_OK;
+}
+}  // namespace
+
 int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X, int64_t ldx, int32_t d,
                              float* Y, int64_t ldy_row, int64_t ldy_hop, const h2gcn_launch_opts* lopts,
                              void* stream_v) {
     try {
         h2gcn_launch_opts lo;
-        memset(&lo, 0, sizeof(lo));
-        if (lopts) {
-            if (lopts->struct_size < 8 || lopts->struct_size > sizeof(lo))
-                return fail(H2GCN_ERR_INVALID_ARGUMENT, "launch opts struct_size = %u", lopts->struct_size);
-            memcpy(&lo, lopts, lopts->struct_size);
-        }
-        if (lo.flags & ~(uint32_t)H2GCN_LAUNCH_RELU) return fail(H2GCN_ERR_INVALID_ARGUMENT, "unknown launch flags 0x%x", lo.flags);
-        void* workspace = lo.workspace_dev;
-        const size_t workspace_bytes = lo.workspace_bytes;
+        int st = read_launch_opts(lopts, &lo);
+        if (st != H2GCN_OK) return st;
         if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
         uint32_t mask;
-        int st = resolve_mask(plan, hop_mask, &mask);
+        st = resolve_mask(plan, hop_mask, &mask);
         if (st != H2GCN_OK) return st;
         if ((st = check_device(plan)) != H2GCN_OK) return st;
         if (d < 1) return fail(H2GCN_ERR_INVALID_ARGUMENT, "d = %d", d);
@@ -622,22 +700,22 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
         if (ldy_hop < 0 || ldy_row < 0) return fail(H2GCN_ERR_INVALID_ARGUMENT, "negative output stride");
         LaunchParams p;
         memset(&p, 0, sizeof(p));
+        LaunchShape sh = shape_of(plan, mask, false);
         int s = 0;
-        int64_t nnz_sel = 0;
-        bool vec_ok = aligned16(X) && aligned16(Y) && ldx % 4 == 0 && ldy_row % 4 == 0;
+        bool dst_vec_ok = aligned16(Y) && ldy_row % 4 == 0;
         for (int k = 0; k < plan->n_hops; ++k) {
             if (!(mask & (1u << k))) continue;
             const HopOperand& op = plan->fwd[k];
-            nnz_sel += op.nnz;
             p.hop[s] = HopCsr{op.rowptr, op.colidx, op.vals};
             p.src_hop_off[s] = 0;
             p.dst_hop_off[s] = (int64_t)s * ldy_hop;
-            vec_ok = vec_ok && (p.dst_hop_off[s] % 4 == 0);
+            dst_vec_ok = dst_vec_ok && (p.dst_hop_off[s] % 4 == 0);
             ++s;
         }
         p.n_sel = s;
         if (s > 1 && ldy_hop < d) return fail(H2GCN_ERR_INVALID_ARGUMENT, "ldy_hop = %lld < d = %d: hop outputs would overlap", (long long)ldy_hop, d);
         p.d = d;
+        p.d_src = d;
         p.n_rows = plan->n_rows;
         p.src = X;
         p.ld_src = ldx;
@@ -655,23 +733,18 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
         // 32-bit gather offsets when the farthest byte of X is below 4 GiB
         bool off32 = ((double)(plan->n_cols > 0 ? plan->n_cols - 1 : 0) * (double)ldx + d) * 4.0 < 4294967296.0;
         int forced_slice = plan->slice_cols;
-        const int rs = (workspace && vec_ok && aligned16(workspace)) ? repack_slice_cols(plan, nnz_sel, s, ldx, d) : 0;
-        if (rs > 0 && workspace_bytes >= (size_t)plan->n_cols * (size_t)((d + rs - 1) / rs) * (size_t)rs * 4) {
-            // slice-major scratch copy of X, then gather slice q from the contiguous block W[q] = [n_cols, rs]
-            const int n_slices = (d + rs - 1) / rs;
-            const int64_t total = plan->n_cols * (int64_t)n_slices * (rs / 4);
-            const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 64);
-            hipLaunchKernelGGL(h2gcn::repack_slice_major_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_v, X, ldx,
-                               plan->n_cols, (int)d, n_slices, rs, (float*)workspace);
+        bool src_vec_ok = source_vec_ok(X, ldx, 0, s, false);
+        sh.src_vec_ok = src_vec_ok;
+        sh.ld_src = ldx;
+        sh.d = d;
+        const int rs = (lo.workspace_dev && aligned16(lo.workspace_dev)) ? scratch_slice_cols(plan, sh) : 0;
+        if (rs > 0 && lo.workspace_bytes >= scratch_bytes(sh, rs)) {
+            use_scratch(p, sh, rs, src_vec_ok, 0, lo.workspace_dev, (hipStream_t)stream_v, &off32);
             H2GCN_HIP_TRY(hipGetLastError());
-            p.src = (const float*)workspace;
-            p.ld_src = rs;
-            p.src_slice_stride = plan->n_cols * (int64_t)rs;
             forced_slice = rs;
-            off32 = (double)plan->n_cols * (double)n_slices * rs * 4.0 < 4294967296.0;
+            src_vec_ok = true;
         }
-        return launch<false>(p, plan->variant, vec_ok, off32, forced_slice, plan->n_cols,
-                             (double)nnz_sel / ((double)p.n_rows * s), (hipStream_t)stream_v);
+        return launch<false>(p, plan->variant, src_vec_ok, dst_vec_ok, off32, forced_slice, plan->n_cols, sh.avg, (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_opts_f32");
     }
@@ -679,12 +752,22 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
 
 int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* dY, int64_t ldg_row,
                           int64_t ldg_hop, int32_t d, float* dX, int64_t ldx, void* stream_v) {
+    return h2gcn_spmm_hops_T_opts_f32(plan, hop_mask, dY, ldg_row, ldg_hop, d, dX, ldx, nullptr, stream_v);
+}
+
+int h2gcn_spmm_hops_T_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* dY, int64_t ldg_row,
+                               int64_t ldg_hop, int32_t d, float* dX, int64_t ldx, const h2gcn_launch_opts* lopts,
+                               void* stream_v) {
     try {
+        h2gcn_launch_opts lo;
+        int st = read_launch_opts(lopts, &lo);
+        if (st != H2GCN_OK) return st;
+        if (lo.bias_dev || lo.flags) return fail(H2GCN_ERR_INVALID_ARGUMENT, "the adjoint launch has no epilogue (bias / flags must be 0)");
         if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
         if (!plan->has_transpose)
             return fail(H2GCN_ERR_NO_TRANSPOSE, "plan was created without H2GCN_PLAN_BUILD_TRANSPOSE");
         uint32_t mask;
-        int st = resolve_mask(plan, hop_mask, &mask);
+        st = resolve_mask(plan, hop_mask, &mask);
         if (st != H2GCN_OK) return st;
         if ((st = check_device(plan)) != H2GCN_OK) return st;
         if (d < 1) return fail(H2GCN_ERR_INVALID_ARGUMENT, "d = %d", d);
@@ -695,21 +778,19 @@ int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const flo
         if (ldg_row < d || ldg_hop < 0) return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad gradient strides");
         LaunchParams p;
         memset(&p, 0, sizeof(p));
+        LaunchShape sh = shape_of(plan, mask, true);
         int s = 0;
-        int64_t nnz_sel = 0;
-        bool vec_ok = aligned16(dY) && aligned16(dX) && ldx % 4 == 0 && ldg_row % 4 == 0;
         for (int k = 0; k < plan->n_hops; ++k) {
             if (!(mask & (1u << k))) continue;
             const HopOperand& op = plan->adj[k];
-            nnz_sel += op.nnz;
             p.hop[s] = HopCsr{op.rowptr, op.colidx, op.vals};
             p.src_hop_off[s] = (int64_t)s * ldg_hop;
             p.dst_hop_off[s] = 0;
-            vec_ok = vec_ok && (p.src_hop_off[s] % 4 == 0);
             ++s;
         }
         p.n_sel = s;
         p.d = d;
+        p.d_src = d;
         p.n_rows = plan->n_cols;
         p.src = dY;
         p.ld_src = ldg_row;
@@ -722,9 +803,21 @@ int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const flo
         const int64_t rows_per_tile = (int64_t)p.rows_per_wave * h2gcn::kWavesPerBlock;
         p.n_tiles = (p.n_rows + rows_per_tile - 1) / rows_per_tile;
         p.tiles_per_xcd = (p.n_tiles + h2gcn::kNumXcd - 1) / h2gcn::kNumXcd;
-        const bool off32 = ((double)(plan->n_rows > 0 ? plan->n_rows - 1 : 0) * (double)ldg_row + (double)(s - 1) * (double)ldg_hop + d) * 4.0 < 4294967296.0;
-        return launch<true>(p, plan->variant, vec_ok, off32, plan->slice_cols, plan->n_rows,
-                            (double)nnz_sel / ((double)p.n_rows * s), (hipStream_t)stream_v);
+        bool off32 = ((double)(plan->n_rows > 0 ? plan->n_rows - 1 : 0) * (double)ldg_row + (double)(s - 1) * (double)ldg_hop + d) * 4.0 < 4294967296.0;
+        const bool dst_vec_ok = aligned16(dX) && ldx % 4 == 0;
+        bool src_vec_ok = source_vec_ok(dY, ldg_row, ldg_hop, s, true);
+        int forced_slice = plan->slice_cols;
+        sh.src_vec_ok = src_vec_ok;
+        sh.ld_src = ldg_row;
+        sh.d = d;
+        const int rs = (lo.workspace_dev && aligned16(lo.workspace_dev) && plan->n_rows > 0) ? scratch_slice_cols(plan, sh) : 0;
+        if (rs > 0 && lo.workspace_bytes >= scratch_bytes(sh, rs)) {
+            use_scratch(p, sh, rs, src_vec_ok, ldg_hop, lo.workspace_dev, (hipStream_t)stream_v, &off32);
+            H2GCN_HIP_TRY(hipGetLastError());
+            forced_slice = rs;
+            src_vec_ok = true;
+        }
+        return launch<true>(p, plan->variant, src_vec_ok, dst_vec_ok, off32, forced_slice, plan->n_rows, sh.avg, (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_T_f32");
     }

@@ -19,13 +19,19 @@
 //     over the 4 waves of a workgroup: LDS-staged partial sums, summed in fixed wave order (deterministic);
 //   * the block -> row-tile map gives every XCD (private L2) a contiguous range of rows.
 //
-// Floating point: fp32 multiply-add per nonzero.  Inside a lane group the accumulation order is ascending
-// column order, as in the reference's CPU kernel; the G group partials (and the 4 wave partials of a long
-// segment) are then added in a fixed tree, which is the only reordering vs. a sequential sum.  The order depends on
-// the row's own nonzeros and on two schedule parameters -- the slice width (it fixes G = 64 / (slice/4)) and the
-// long-row threshold -- never on grid geometry, rows_per_wave, the segment-walk variant or the row partition.  A
-// row-partitioned multi-GPU run that uses the same slice / feature-chunk widths therefore reproduces the single-GPU
-// result bit-for-bit; runs with different widths agree to rounding (~1e-7), not bitwise.
+// Floating point: fp32 multiply-add per nonzero, ONE CANONICAL SUMMATION TREE per output element:
+//     neighbour j of a (row, hop) segment (j = its position in the row's ascending column order, the reference's
+//     order) is added, in ascending j, into partial  P[j mod 4];  the row's value is  (P0 + P1) + (P2 + P3).
+// Every kernel in this file produces exactly that tree whatever its lane geometry: with 64-column slices the four
+// lane groups of a wave each own one partial and the fold is v_permlane16_swap / v_permlane32_swap; with 128-column
+// slices a lane group keeps two partials in registers (even / odd steps), with 256-column slices and in the generic
+// column-tiled kernel a lane keeps all four; the short-row mode keeps four per lane group.  (A segment with >=
+// long_row_threshold nonzeros is split over the 4 waves of a workgroup in 64-neighbour chunks: each wave builds the
+// same tree over its chunks, the 4 wave totals are added in wave order.)  The bits of Y therefore depend only on the
+// row's own nonzeros and on long_row_threshold -- never on the slice / feature-chunk width, the scratch copy, the
+// segment-walk variant, grid geometry, rows_per_wave or the row partition: a P-GPU run reproduces the 1-GPU result
+// bit-for-bit with ANY chunking (SURVEY.md 8(e) "Determinism").  Only the narrow slices (32 / 16 columns: 8 / 16 lane
+// groups, used for d < 64) have their own wider tree; the launcher never picks them for d >= 64.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -49,7 +55,20 @@ constexpr int kMinWavesPerSimd = H2GCN_MIN_WAVES;
 #ifndef H2GCN_SHORT_MIN_WAVES
 #define H2GCN_SHORT_MIN_WAVES 4
 #endif  // __launch_bounds__ of the fast paths (waves per SIMD the register budget must allow)
+#ifndef H2GCN_WIDE_MIN_WAVES
+#define H2GCN_WIDE_MIN_WAVES H2GCN_MIN_WAVES
+#endif  // ... of the 128 / 256-column slices, whose lanes keep 2 / 4 partials of the canonical tree
 constexpr int kMaxTileCols = 256;   // columns one pass of a wave covers at most (64 lanes x float4)
+constexpr int kTreeParts = 4;       // partials of the canonical summation tree (see the header comment)
+
+// NP = partials a lane keeps for the canonical tree: the G = 64/LPR lane groups of a wave own G of the 4 partials per
+// step, so a lane cycles through 4/G of them (G >= 4: one -- for G = 4 that IS the canonical tree; G = 8, 16: the
+// narrow-slice tree)
+template <int LPR>
+struct Tree {
+    static constexpr int G = kWave / LPR;
+    static constexpr int NP = G >= kTreeParts ? 1 : kTreeParts / G;
+};
 
 struct HopCsr {
     const int64_t* rowptr;
@@ -62,7 +81,9 @@ struct LaunchParams {
     int64_t src_hop_off[H2GCN_MAX_HOPS]; // element offset added to the gather source for hop s
     int64_t dst_hop_off[H2GCN_MAX_HOPS]; // element offset added to the output for hop s (ignored in SUM mode)
     int n_sel;
-    int d;
+    int d;           // feature columns of the output
+    int d_src;       // valid columns of the gather source (== d, or the zero-padded width of a scratch copy)
+    int dst_scalar;  // general-store kernels: store element-wise with a column bound (d % 4 != 0 / unaligned output)
     int64_t n_rows;  // rows of the output
     const float* src;
     int64_t ld_src;
@@ -143,6 +164,29 @@ __device__ __forceinline__ float fold_groups(float v) {
     return v;
 }
 
+// The row total out of the partials a lane holds (see Tree<LPR>): afterwards every lane group holds the total.
+//   G = 1: (P0 + P1) + (P2 + P3) in registers;  G = 2: group g holds P[g], P[g+2] -> fold each across the groups, add;
+//   G = 4: group g holds P[g] -> fold_groups: (g, g^1) then (g, g^2) = (P0 + P1) + (P2 + P3).
+template <int VEC, int LPR, int NP>
+__device__ __forceinline__ void fold_tree(const float (&acc)[NP][VEC], float (&tot)[VEC]) {
+    constexpr int G = kWave / LPR;
+    static_assert(NP == Tree<LPR>::NP, "partials per lane");
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        if constexpr (G == 1) tot[i] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+        else if constexpr (G == 2) tot[i] = fold_xor32(acc[0][i]) + fold_xor32(acc[1][i]);
+        else tot[i] = fold_groups<LPR>(acc[0][i]);
+    }
+}
+
+template <int VEC, int NP>
+__device__ __forceinline__ void zero_acc(float (&acc)[NP][VEC]) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
+}
+
 template <int VEC>
 __device__ __forceinline__ typename VecT<VEC>::type load_vec(const float* p) {
 #ifdef H2GCN_NT_GATHER
@@ -184,9 +228,9 @@ struct GatherAddr {
 // The cross-lane reads of (c, v) always run with the full wave active (ds_bpermute returns 0 for a source
 // lane that is masked off); only the gather itself is predicated, by `take` (false on lanes whose slot is
 // padding -- they must not touch src: 0 * Inf would poison the row).
-template <int VEC, int LPR, int U, bool PREDICATED, bool OFF32>
+template <int VEC, int LPR, int U, bool PREDICATED, bool OFF32, int PHASE = 0, int NP>
 __device__ __forceinline__ void gather_batch(int c, float v, int t, int g, const GatherAddr<OFF32>& addr, bool take,
-                                             float (&acc)[VEC]) {
+                                             float (&acc)[NP][VEC]) {
     constexpr int G = kWave / LPR;
     typename VecT<VEC>::type x[U];
     float w[U];
@@ -214,8 +258,10 @@ __device__ __forceinline__ void gather_batch(int c, float v, int t, int g, const
             x[u] = load_vec<VEC>(p);
         }
     }
+    // step t+u serves neighbour (t+u)*G + g -> canonical partial ((t+u)*G + g) % 4 = lane-local partial (t+u) % NP;
+    // the caller states t % NP as PHASE, so the partial of every step is a compile-time register choice
 #pragma unroll
-    for (int u = 0; u < U; ++u) fma_vec<VEC>(acc, w[u], x[u]);
+    for (int u = 0; u < U; ++u) fma_vec<VEC>(acc[(PHASE + u) % NP], w[u], x[u]);
 }
 
 // (column id, value) of neighbour `lane` of the 64-wide chunk starting at `base` (zero beyond the segment end)
@@ -236,12 +282,12 @@ __device__ __forceinline__ void load_chunk(const int32_t* __restrict__ colidx, c
 #ifndef H2GCN_MAIN_MAXB
 #define H2GCN_MAIN_MAXB 8
 #endif
-template <int VEC, int LPR, bool MASKED, bool OFF32, int MAXB = H2GCN_MAIN_MAXB>
+template <int VEC, int LPR, bool MASKED, bool OFF32, int MAXB = H2GCN_MAIN_MAXB, int NP>
 __device__ __forceinline__ void process_chunk(int c, float v, int n, int g, const GatherAddr<OFF32>& addr,
-                                              bool lane_active, float (&acc)[VEC]) {
+                                              bool lane_active, float (&acc)[NP][VEC]) {
     constexpr int G = kWave / LPR;
     const int full = n / G;  // steps in which every lane group has a neighbour
-    int t = 0;
+    int t = 0;               // batches of 8 / 4 start at t % 4 == 0: partial phase 0
     if constexpr (MAXB >= 8)
         for (; t + 8 <= full; t += 8) gather_batch<VEC, LPR, 8, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
     if constexpr (MAXB < 8)
@@ -250,30 +296,39 @@ __device__ __forceinline__ void process_chunk(int c, float v, int n, int g, cons
         gather_batch<VEC, LPR, 4, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
         t += 4;
     }
+    // the last 0..3 full steps and (G > 1) the ragged step in which only the first (n - full*G) groups still have a
+    // neighbour, with the phase of every step spelled out
+    const int rem = n - full * G;
     if (t + 2 <= full) {
         gather_batch<VEC, LPR, 2, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
         t += 2;
-    }
-    if (t + 1 <= full) {
+        if (t + 1 <= full) {
+            gather_batch<VEC, LPR, 1, MASKED, OFF32, 2 % NP>(c, v, t, g, addr, lane_active, acc);
+            if constexpr (G > 1)
+                if (rem > 0) gather_batch<VEC, LPR, 1, true, OFF32, 3 % NP>(c, v, full, g, addr, lane_active && g < rem, acc);
+        } else {
+            if constexpr (G > 1)
+                if (rem > 0) gather_batch<VEC, LPR, 1, true, OFF32, 2 % NP>(c, v, full, g, addr, lane_active && g < rem, acc);
+        }
+    } else if (t + 1 <= full) {
         gather_batch<VEC, LPR, 1, MASKED, OFF32>(c, v, t, g, addr, lane_active, acc);
-        t += 1;
-    }
-    if constexpr (G > 1) {
-        // ragged last step: only the first (n - full*G) groups still have a neighbour
-        const int rem = n - full * G;
-        if (rem > 0) gather_batch<VEC, LPR, 1, true, OFF32>(c, v, full, g, addr, lane_active && g < rem, acc);
+        if constexpr (G > 1)
+            if (rem > 0) gather_batch<VEC, LPR, 1, true, OFF32, 1 % NP>(c, v, full, g, addr, lane_active && g < rem, acc);
+    } else {
+        if constexpr (G > 1)
+            if (rem > 0) gather_batch<VEC, LPR, 1, true, OFF32>(c, v, full, g, addr, lane_active && g < rem, acc);
     }
 }
 
 // Accumulate sum_j val_j * src[col_j, :] over the nonzeros [seg_begin, seg_end) of one CSR row, taking the
 // 64-wide chunks chunk0, chunk0+chunk_step, ... (regular path: all of them; long path: this wave's share).
 // Each lane group accumulates its neighbours in ascending order into acc.
-template <int VEC, int LPR, bool MASKED, bool OFF32, int MAXB = H2GCN_MAIN_MAXB>
+template <int VEC, int LPR, bool MASKED, bool OFF32, int MAXB = H2GCN_MAIN_MAXB, int NP>
 __device__ __forceinline__ void accumulate_segment(const int32_t* __restrict__ colidx,
                                                    const float* __restrict__ vals, int64_t seg_begin,
                                                    int64_t seg_end, int chunk0, int chunk_step,
                                                    const GatherAddr<OFF32>& addr, int lane, bool lane_active,
-                                                   float (&acc)[VEC]) {
+                                                   float (&acc)[NP][VEC]) {
     const int g = lane / LPR;
     for (int64_t base = seg_begin + (int64_t)chunk0 * kWave; base < seg_end; base += (int64_t)chunk_step * kWave) {
         const int64_t left = seg_end - base;
@@ -289,12 +344,12 @@ __device__ __forceinline__ void accumulate_segment(const int32_t* __restrict__ c
 // still gathering, and every further chunk is fetched before the current one is processed -- the index fetch
 // latency leaves the per-segment dependency chain (index -> gather -> fold -> store), which is what bounds
 // short rows.  Loads retire in order, so waiting for the gathers implies the prefetch has landed.
-template <int VEC, int LPR, bool OFF32>
+template <int VEC, int LPR, bool OFF32, int NP>
 __device__ __forceinline__ void accumulate_segment_prefetched(const int32_t* __restrict__ colidx,
                                                               const float* __restrict__ vals, int64_t seg_begin,
                                                               int64_t seg_end, int c, float v,
                                                               const GatherAddr<OFF32>& addr, int lane,
-                                                              float (&acc)[VEC]) {
+                                                              float (&acc)[NP][VEC]) {
     const int g = lane / LPR;
     for (int64_t base = seg_begin; base < seg_end; base += kWave) {
         const int64_t left = seg_end - base;
@@ -313,17 +368,15 @@ __device__ __forceinline__ void accumulate_segment_prefetched(const int32_t* __r
 // a whole wave to one segment leaves the kernel latency-bound: one segment = one dependent chain index -> gather ->
 // fold -> store with a single 1 KiB load in flight.  Here the G lane groups of a wave take G DIFFERENT segments
 // (same hop, G consecutive rows) and walk them in lock step: G segments' gathers are in flight together and no
-// cross-lane fold is needed.  The arithmetic is arranged to be BIT-IDENTICAL to the wave-per-segment mode: that mode
-// sums neighbour j into the partial of lane group j % G and then folds the partials in a fixed tree; a group here
-// keeps the same G partials in registers and combines them in the same tree -- so which mode served a row can never
+// cross-lane fold is needed.  The arithmetic is the canonical tree of the header comment: a group keeps the four
+// partials P[j mod 4] in registers and combines them as (P0 + P1) + (P2 + P3) -- so which mode served a row can never
 // be seen in the result (row partitions, rows_per_wave and tile geometry stay invisible).
 // Handles segments of at most LPR nonzeros (one index fetch per group): `c`, `v` hold the group's indices/values
 // lane-wise (lane li of the group = neighbour li), `n_mine` its length, `n_max` the longest of the round (uniform).
 template <int VEC, int LPR, bool OFF32>
 __device__ __forceinline__ void accumulate_grouped(int c, float v, int n_mine, int n_max, int lane,
-                                                   const GatherAddr<OFF32>& addr, float (&part)[kWave / LPR][VEC]) {
-    constexpr int G = kWave / LPR;
-    constexpr int U = G < 4 ? 4 : G;  // neighbours per batch (a multiple of G so that j % G is a compile-time constant)
+                                                   const GatherAddr<OFF32>& addr, float (&part)[kTreeParts][VEC]) {
+    constexpr int U = kTreeParts;  // neighbours per batch: neighbour t+u (t % 4 == 0) -> canonical partial u
     const int group_base = lane & ~(LPR - 1);
     for (int t = 0; t < n_max; t += U) {
         typename VecT<VEC>::type x[U];
@@ -341,19 +394,15 @@ __device__ __forceinline__ void accumulate_grouped(int c, float v, int n_mine, i
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (t + u < n_mine) fma_vec<VEC>(part[u % G], w[u], x[u]);
+            if (t + u < n_mine) fma_vec<VEC>(part[u], w[u], x[u]);
     }
 }
 
-// the fixed tree of fold_groups<LPR>, applied to partials held in registers: G = 2: p0 + p1; G = 4: (p0+p1) + (p2+p3)
-template <int VEC, int G>
-__device__ __forceinline__ void combine_partials(const float (&part)[G][VEC], float (&acc)[VEC]) {
-    static_assert(G == 2 || G == 4, "short-row mode supports 2 or 4 lane groups");
+// the canonical tree applied to partials held in registers: (p0 + p1) + (p2 + p3)
+template <int VEC>
+__device__ __forceinline__ void combine_partials(const float (&part)[kTreeParts][VEC], float (&acc)[VEC]) {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        if constexpr (G == 2) acc[i] = part[0][i] + part[1][i];
-        else acc[i] = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
-    }
+    for (int i = 0; i < VEC; ++i) acc[i] = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
 }
 
 // Optional fused epilogue of the store (reference SparseDense.call, h2gcn/models/_layers.py:45-52: `+ bias`, then the
@@ -382,28 +431,59 @@ __device__ __forceinline__ void store_vec(float* p, const float (&acc)[VEC]) {
     }
 }
 
+// Store of one lane's VEC finished sums, columns col .. col+VEC-1 of an output row (`ptr` points at column col).
+// Plain kernels: one 16-byte store when the whole vector lies inside d (`whole`).  General-store kernels (GEN) add the
+// bias / ReLU epilogue and, for outputs that are not 16-byte addressable or d % 4 != 0 (p.dst_scalar), element-wise
+// stores bounded by d -- which is how odd feature widths (reference: any b.shape[1], _layers.py:62-76) run on the
+// float4 gather kernels.
+template <int VEC, bool GEN, typename P>
+__device__ __forceinline__ void store_out(const P& p, float* ptr, int col, float (&tot)[VEC], bool whole) {
+    if constexpr (GEN) {
+        if (p.dst_scalar) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                if (col + i < p.d) {
+                    float t = tot[i];
+                    if (p.bias) t += p.bias[col + i];
+                    if (p.relu) t = fmaxf(t, 0.f);
+                    __builtin_nontemporal_store(t, ptr + i);
+                }
+            }
+            return;
+        }
+        if (whole) {
+            epilogue<VEC>(tot, p.bias, p.relu, col);
+            store_vec<VEC>(ptr, tot);
+        }
+    } else {
+        if (whole) store_vec<VEC>(ptr, tot);
+    }
+}
+
 // VEC    floats per lane per gathered row (4 on the fast paths)
 // LPR    lanes that cover one gathered row
 // EXACT  the launch covers the feature columns in n_slices = ceil(d / (VEC*LPR)) slices of VEC*LPR columns,
 //        slice-major (all row tiles of slice 0, then slice 1, ...: while a slice is being processed the gather
 //        working set is n_cols * slice_cols * 4 bytes, which is what the 256 MiB Infinity Cache sees).  A last
-//        slice that sticks out beyond d (d % 4 == 0 but not a multiple of the slice) costs no predication: the
-//        lanes beyond d re-read the last valid float4 of the row (same cache line, no extra traffic) and simply do
-//        not store.  Otherwise (!EXACT) LPR == 64 and each wave loops over masked column tiles (any d, any alignment)
+//        slice that sticks out beyond the source's valid columns costs no predication: the lanes beyond re-read the
+//        last valid float4 of the row (same cache line, no extra traffic) and simply do not store.  Otherwise (!EXACT)
+//        LPR == 64 and each wave loops over masked column tiles (any d, any alignment)
 // SUM    adjoint mode: one output row = sum over the selected hops
 // OFF32  32-bit gather offsets (see GatherAddr)
 // SHORT  short-row mode (see accumulate_grouped): rounds of G segments whose lengths are all <= LPR are served one
 //        lane group per segment; other rounds fall back to the wave-per-segment walk.  Same bits either way.
-// EPI    the store applies the optional bias / ReLU epilogue (separate instantiations: the epilogue's registers would
-//        otherwise push the 6-waves-per-SIMD variants of the plain aggregation into spilling)
+// EPI    general store (see store_out): optional bias / ReLU epilogue, element-wise bounded stores for odd widths and
+//        unaligned outputs (separate instantiations: the extra registers would otherwise push the 6-waves-per-SIMD
+//        variants of the plain aggregation into spilling)
 // FB     (short-row kernels) deepest load batch of the wave-per-segment fallback: 4 keeps the kernel at 7 waves per SIMD
 //        (memory-resident operands: occupancy buys bandwidth), 8 at 5 (cache-resident operands: the longer segments'
 //        loads in flight matter more)
 template <int VEC, int LPR, bool EXACT, bool SUM, bool OFF32, bool PIPE = false, bool SHORT = false, bool EPI = false, int FB = 8>
-__global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kMinWavesPerSimd) : 2) void spmm_hops_kernel(const LaunchParams p) {
+__global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : (LPR >= 32 ? H2GCN_WIDE_MIN_WAVES : kMinWavesPerSimd)) : 2) void spmm_hops_kernel(const LaunchParams p) {
     static_assert(EXACT || LPR == kWave, "column-tiled path uses the whole wave per row");
     __shared__ float partial[kWavesPerBlock][kMaxTileCols];
     using off_t = typename std::conditional<OFF32, uint32_t, int64_t>::type;
+    constexpr int NP = Tree<LPR>::NP;
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = wave_uniform(threadIdx.x >> 6);
@@ -418,10 +498,11 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kM
     const int col_begin = EXACT ? slice * (VEC * LPR) : 0;
     const int col_end = EXACT ? col_begin + VEC * LPR : p.d;
     const int64_t src_col_begin = EXACT ? (int64_t)slice * p.src_slice_stride : 0;  // where this slice starts in the source
-    // EXACT: lanes of the (possibly partial) last slice that lie beyond d gather the last valid float4 instead
-    const int valid_lanes = EXACT ? min(LPR, (p.d - col_begin) / VEC) : LPR;
+    // EXACT: lanes of the (possibly partial) last slice that lie beyond the source's valid columns gather the last
+    // valid float4 instead; `whole` = this lane's float4 lies inside d (it may store with one 16-byte store)
+    const int valid_lanes = EXACT ? min(LPR, (p.d_src - col_begin) / VEC) : LPR;
     const int li_src = EXACT ? min(li, valid_lanes - 1) : li;
-    const bool store_ok = !EXACT || li < valid_lanes;
+    const bool whole = !EXACT || (col_begin + li * VEC + VEC <= p.d);
 
     if (b < p.n_long) {
         // ---- long segment: the 4 waves of this workgroup share one (row, hop) [forward] / one row [SUM] ----
@@ -431,9 +512,8 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kM
         const int s_last = SUM ? n_sel : s_first + 1;
         for (int col0 = col_begin; col0 < col_end; col0 += VEC * LPR) {
             const bool lane_active = EXACT || (col0 + li * VEC < p.d);
-            float acc[VEC];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            float acc[NP][VEC];
+            zero_acc<VEC, NP>(acc);
             for (int s = s_first; s < s_last; ++s) {
                 const HopCsr& h = p.hop[s];
                 const int64_t sb = h.rowptr[row], se = h.rowptr[row + 1];
@@ -442,14 +522,14 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kM
                 accumulate_segment<VEC, LPR, !EXACT, OFF32>(h.colidx, h.vals, sb, se, wave, kWavesPerBlock, addr, lane,
                                                             lane_active, acc);
             }
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
+            float tot[VEC];
+            fold_tree<VEC, LPR, NP>(acc, tot);
             if (g == 0) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) partial[wave][li * VEC + i] = acc[i];
+                for (int i = 0; i < VEC; ++i) partial[wave][li * VEC + i] = tot[i];
             }
             __syncthreads();
-            // fixed-order sum of the 4 wave partials; thread c owns column col0 + c
+            // fixed-order sum of the 4 wave totals; thread c owns column col0 + c
             const int c = threadIdx.x;
             if (c < VEC * LPR && col0 + c < p.d) {
                 float t = partial[0][c];
@@ -495,9 +575,8 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kM
         const GatherAddr<OFF32> addr0{nullptr, (off_t)(li_src * VEC * 4), (off_t)(p.ld_src * 4)};
         // wave-per-segment walk of one row (all hops in SUM mode, hop `s_only` otherwise) -- the general path
         auto row_wave_wide = [&](int r, int s_first, int s_last) {
-            float acc[VEC];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            float acc[NP][VEC];
+            zero_acc<VEC, NP>(acc);
             if constexpr (SUM) {
                 for (int s = s_first; s < s_last; ++s) {
                     const int l0 = s * (rpw + 1) + r;
@@ -513,20 +592,19 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kM
                 addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin);
                 accumulate_segment<VEC, LPR, false, OFF32, FB>(h.colidx, h.vals, sb, se, 0, 1, addr, lane, true, acc);
                 if constexpr (!SUM) {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
-                    if (g == 0 && store_ok) {
-                        if constexpr (EPI) epilogue<VEC>(acc, p.bias, p.relu, col_begin + li * VEC);
-                        store_vec<VEC>(p.dst + (row0 + r) * p.ld_dst + p.dst_hop_off[s] + col_begin + li * VEC, acc);
-                    }
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+                    float tot[VEC];
+                    fold_tree<VEC, LPR, NP>(acc, tot);
+                    if (g == 0)
+                        store_out<VEC, EPI>(p, p.dst + (row0 + r) * p.ld_dst + p.dst_hop_off[s] + col_begin + li * VEC,
+                                            col_begin + li * VEC, tot, whole);
+                    zero_acc<VEC, NP>(acc);
                 }
             }
             if constexpr (SUM) {
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
-                if (g == 0 && store_ok) store_vec<VEC>(p.dst + (row0 + r) * p.ld_dst + col_begin + li * VEC, acc);
+                float tot[VEC];
+                fold_tree<VEC, LPR, NP>(acc, tot);
+                if (g == 0)
+                    store_out<VEC, EPI>(p, p.dst + (row0 + r) * p.ld_dst + col_begin + li * VEC, col_begin + li * VEC, tot, whole);
             }
         };
         // (begin, length) of the segment (hop s, row b*G + g) for this lane's group; length -1 for rows beyond the tile
@@ -570,20 +648,16 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kM
                     int n_max = 0;
 #pragma unroll
                     for (int gg = 0; gg < G; ++gg) n_max = max(n_max, __builtin_amdgcn_readlane(len, gg * LPR));
-                    float part[G][VEC];
-#pragma unroll
-                    for (int gg = 0; gg < G; ++gg)
-#pragma unroll
-                        for (int i2 = 0; i2 < VEC; ++i2) part[gg][i2] = 0.f;
+                    float part[kTreeParts][VEC];
+                    zero_acc<VEC, kTreeParts>(part);
                     GatherAddr<OFF32> addr = addr0;
                     addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin);
                     accumulate_grouped<VEC, LPR, OFF32>(c, v, len, n_max, lane, addr, part);
-                    float acc[VEC];
-                    combine_partials<VEC, G>(part, acc);
-                    if (len >= 0 && store_ok) {
-                        if constexpr (EPI) epilogue<VEC>(acc, p.bias, p.relu, col_begin + li * VEC);
-                        store_vec<VEC>(p.dst + (row0 + blk * G + g) * p.ld_dst + p.dst_hop_off[s] + col_begin + li * VEC, acc);
-                    }
+                    float tot[VEC];
+                    combine_partials<VEC>(part, tot);
+                    if (len >= 0)
+                        store_out<VEC, EPI>(p, p.dst + (row0 + blk * G + g) * p.ld_dst + p.dst_hop_off[s] + col_begin + li * VEC,
+                                            col_begin + li * VEC, tot, whole);
                 } else {
                     for (int gg = 0; gg < G && blk * G + gg < rows_here; ++gg) row_wave_wide(blk * G + gg, s, s + 1);
                 }
@@ -619,11 +693,8 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kM
             for (int blk = 0; blk < n_blocks; ++blk) {
                 const bool nxt_short = blk + 1 < n_blocks && block_short(blk + 1);
                 if (cur_short) {
-                    float part[G][VEC];
-#pragma unroll
-                    for (int gg = 0; gg < G; ++gg)
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) part[gg][i] = 0.f;
+                    float part[kTreeParts][VEC];
+                    zero_acc<VEC, kTreeParts>(part);
                     bool valid = false;
                     for (int s = 0; s < n_sel; ++s) {
                         const int len = len_n, c = c_n;
@@ -638,9 +709,10 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kM
                         addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin);
                         accumulate_grouped<VEC, LPR, OFF32>(c, v, len, n_max, lane, addr, part);
                     }
-                    float acc[VEC];
-                    combine_partials<VEC, G>(part, acc);
-                    if (valid && store_ok) store_vec<VEC>(p.dst + (row0 + blk * G + g) * p.ld_dst + col_begin + li * VEC, acc);
+                    float tot[VEC];
+                    combine_partials<VEC>(part, tot);
+                    if (valid)
+                        store_out<VEC, EPI>(p, p.dst + (row0 + blk * G + g) * p.ld_dst + col_begin + li * VEC, col_begin + li * VEC, tot, whole);
                 } else {
                     if (blk + 1 < n_blocks) fetch(blk + 1, 0, nxt_short);
                     for (int gg = 0; gg < G && blk * G + gg < rows_here; ++gg) row_wave_wide(blk * G + gg, 0, n_sel);
@@ -674,9 +746,8 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kM
         float v_cur, v_nxt = 0.f;
         seg(0, s_nxt, b_nxt, e_nxt);
         load_chunk(p.hop[s_nxt].colidx, p.hop[s_nxt].vals, b_nxt, e_nxt, lane, c_nxt, v_nxt);
-        float acc[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        float acc[NP][VEC];
+        zero_acc<VEC, NP>(acc);
         for (int q = 0; q < n_seg; ++q) {
             s_cur = s_nxt; b_cur = b_nxt; e_cur = e_nxt; c_cur = c_nxt; v_cur = v_nxt;
             if (q + 1 < n_seg) {
@@ -692,15 +763,13 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kM
             const bool skipped = (skip >> q) & 1u;
             if (!SUM || s_cur == n_sel - 1) {
                 if (!skipped) {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
-                    if (g == 0 && store_ok) {
-                        if constexpr (EPI) epilogue<VEC>(acc, p.bias, p.relu, col_begin + li * VEC);
-                        store_vec<VEC>(p.dst + row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_cur]) + col_begin + li * VEC, acc);
-                    }
+                    float tot[VEC];
+                    fold_tree<VEC, LPR, NP>(acc, tot);
+                    if (g == 0)
+                        store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_cur]) + col_begin + li * VEC,
+                                            col_begin + li * VEC, tot, whole);
                 }
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+                zero_acc<VEC, NP>(acc);
             }
         }
         return;
@@ -718,9 +787,8 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kM
         }
         for (int col0 = col_begin; col0 < col_end; col0 += VEC * LPR) {
             const bool lane_active = EXACT || (col0 + li * VEC < p.d);
-            float acc[VEC];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            float acc[NP][VEC];
+            zero_acc<VEC, NP>(acc);
             for (int s = 0; s < n_sel; ++s) {
                 const int l0 = s * (rpw + 1) + r;
                 const int64_t sb = seg_bound(l0), se = seg_bound(l0 + 1);
@@ -730,49 +798,62 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : kM
                                              (off_t)(li_src * VEC * 4), (off_t)(p.ld_src * 4)};
                 accumulate_segment<VEC, LPR, !EXACT, OFF32>(h.colidx, h.vals, sb, se, 0, 1, addr, lane, lane_active, acc);
                 if constexpr (!SUM) {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
-                    if (g == 0 && lane_active && store_ok) {
-                        if constexpr (EPI) epilogue<VEC>(acc, p.bias, p.relu, col0 + li * VEC);
-                        store_vec<VEC>(p.dst + row * p.ld_dst + p.dst_hop_off[s] + col0 + li * VEC, acc);
-                    }
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+                    float tot[VEC];
+                    fold_tree<VEC, LPR, NP>(acc, tot);
+                    if (g == 0 && lane_active)
+                        store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + p.dst_hop_off[s] + col0 + li * VEC, col0 + li * VEC, tot, whole);
+                    zero_acc<VEC, NP>(acc);
                 }
             }
             if constexpr (SUM) {
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[i] = fold_groups<LPR>(acc[i]);
-                if (g == 0 && lane_active && store_ok) {
-                    if constexpr (EPI) epilogue<VEC>(acc, p.bias, p.relu, col0 + li * VEC);
-                    store_vec<VEC>(p.dst + row * p.ld_dst + col0 + li * VEC, acc);
-                }
+                float tot[VEC];
+                fold_tree<VEC, LPR, NP>(acc, tot);
+                if (g == 0 && lane_active)
+                    store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + col0 + li * VEC, col0 + li * VEC, tot, whole);
             }
         }
     }
 }
 
-// Row-major X[n_rows, ld] -> slice-major scratch W[n_slices][n_rows][slice_cols] (n_slices = ceil(d / slice_cols),
-// float4 granularity; columns beyond d are written as zeros).  Used in front of the forward launch
+// Gather source -> slice-major scratch.  Source element (row r, hop s, column c) = x[r*ld + s*ld_hop + c]
+// (forward: one "hop", the embedding X; adjoint: the stacked gradient dY[r, s, :]); scratch
+// W[q][s][r][cc] with q = c / slice_cols, cc = c % slice_cols, n_slices = ceil(d / slice_cols); columns beyond d are
+// written as zeros, so every block is a dense, 16-byte addressable, cache-line aligned [n_rows, slice_cols] matrix.
+// Used in front of a launch
 //   * when the row stride of X is a multiple of 1 KiB: gathering a 256-byte slice out of such rows leaves address
 //     bits 8-9 constant during a whole slice pass and the L2 / Infinity Cache index only a quarter of their sets
 //     (d = 256: 0.76 of the roofline row-major, 0.91 slice-major);
-//   * when the rows of X are not cache-line aligned (d = 100, 132, 200 ...): every 256-byte block of the copy is
-//     line-aligned, so a gather touches ceil(d*4/128) lines instead of one more, and the slices are cache-sized.
-__global__ void repack_slice_major_kernel(const float* __restrict__ x, int64_t ld, int64_t n_rows, int d, int n_slices,
-                                          int slice_cols, float* __restrict__ w) {
+//   * when the rows of the source are not cache-line aligned and wide (d = 132, 200, 300 ...): every 256-byte block of
+//     the copy is line-aligned, so a gather touches ceil(d*4/128) lines instead of one more, and the slices are
+//     cache-sized;
+//   * when d % 4 != 0 or the source is not 16-byte addressable (raw feature widths: Cora F = 1433, citeseer 3703;
+//     reference accepts any b.shape[1], _layers.py:62-76): the float4 gather kernels then run on the padded copy
+//     (VEC4 = false: element-wise reads) instead of the generic column-tiled kernel.
+template <bool VEC4>
+__global__ void repack_slice_major_kernel(const float* __restrict__ x, int64_t ld, int64_t ld_hop, int n_hop, int64_t n_rows,
+                                          int d, int n_slices, int slice_cols, float* __restrict__ w) {
     using f4 = float __attribute__((ext_vector_type(4)));
-    const int c4 = slice_cols / 4;
-    const int64_t per_slice = n_rows * c4;
+    constexpr int E = VEC4 ? 4 : 1;             // floats per thread
+    const int cu = slice_cols / E;              // units per scratch row
+    const int64_t per_hop = n_rows * cu;
+    const int64_t per_slice = per_hop * n_hop;
     const int64_t total = per_slice * n_slices;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int q = (int)(i / per_slice);
-        const int64_t r = (i - q * per_slice) / c4;
-        const int c = (int)(i - q * per_slice - r * c4);
-        const int col = q * slice_cols + c * 4;
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (col < d) v = *reinterpret_cast<const f4*>(x + r * ld + col);
-        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(w) + i);
+        const int64_t i1 = i - q * per_slice;
+        const int s = (int)(i1 / per_hop);
+        const int64_t i2 = i1 - s * per_hop;
+        const int64_t r = i2 / cu;
+        const int c = (int)(i2 - r * cu);
+        const int col = q * slice_cols + c * E;
+        const float* src = x + r * ld + s * ld_hop + col;
+        if constexpr (VEC4) {
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (col < d) v = *reinterpret_cast<const f4*>(src);   // d % 4 == 0 here
+            __builtin_nontemporal_store(v, reinterpret_cast<f4*>(w) + i);
+        } else {
+            __builtin_nontemporal_store(col < d ? *src : 0.f, w + i);
+        }
     }
 }
 

@@ -25,6 +25,9 @@ def _require(cond: bool, msg: str) -> None:
 class HopPlan:
     """H hop matrices sharing one row space, resident on one GPU.
 
+    Results are bit-reproducible functions of the operands: every launch builds the library's canonical per-row
+    summation tree (``include/h2gcn_hip.h``), whatever slice width, scratch copy or segment walk the schedule picks.
+
     Parameters
     ----------
     rowptr, colidx, vals : sequences of H CUDA tensors (int64 ``[n_rows+1]``, int32 ``[nnz]``, float32 ``[nnz]``)
@@ -66,6 +69,9 @@ class HopPlan:
         self._handle = C.c_void_p()
         #: let launches use scratch memory for the slice-major copy of X (see h2gcn_spmm_workspace_bytes)
         self.use_workspace = True
+        #: narrowest feature chunk a pipeline may cut (narrower ones would run on the narrow-slice kernels, whose
+        #: summation tree differs from the canonical one)
+        self.min_chunk_cols = 64
 
         L = _capi.lib()
         arr_t = C.c_void_p * H
@@ -141,7 +147,7 @@ class HopPlan:
         ld = int(ld_src) if ld_src is not None else (self.n_selected(hops) * d if adjoint else d)
         _capi.check(L.h2gcn_plan_schedule(self._handle, self._mask(hops), 1 if adjoint else 0, ld, int(d),
                                           C.byref(sc), C.byref(ns), C.byref(pf), C.byref(cp)))
-        return dict(slice_cols=sc.value, n_slices=ns.value, index_prefetch=pf.value == 1,
+        return dict(slice_cols=sc.value, n_slices=ns.value,
                     segment_walk={0: "wave per segment", 1: "wave per segment + index prefetch", 2: "lane group per segment (short rows)"}[pf.value],
                     scratch_copy=bool(cp.value) and self.use_workspace)
 
@@ -187,9 +193,10 @@ class HopPlan:
         mask = self._mask(hops)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            # scratch for the slice-major copy of X the library wants when X's row stride is a multiple of 1 KiB
-            # (0 bytes otherwise); a torch allocation, so it is stream-ordered and capturable in a hipGraph
-            ws_bytes = int(L.h2gcn_spmm_workspace_bytes(self._handle, mask, x.stride(0), d)) if self.use_workspace else 0
+            # scratch for the slice-major copy of X the library wants when X's row stride is a multiple of 1 KiB, when
+            # its rows are wide and not line-aligned, or when d % 4 != 0 / X is not 16-byte addressable (0 bytes
+            # otherwise); a torch allocation, so it is stream-ordered and capturable in a hipGraph
+            ws_bytes = int(L.h2gcn_spmm_workspace_bytes(self._handle, mask, 0, C.c_void_p(x.data_ptr()), x.stride(0), 0, d)) if self.use_workspace else 0
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device) if ws_bytes else None
             opts = None
             if ws is not None or bias is not None or relu:
@@ -221,9 +228,18 @@ class HopPlan:
         L = _capi.lib()
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            st = L.h2gcn_spmm_hops_T_f32(self._handle, self._mask(hops), C.c_void_p(grad.data_ptr()),
-                                         grad.stride(0) if self.n_rows > 0 else d, grad.stride(1), d,
-                                         C.c_void_p(dx.data_ptr()), dx.stride(0), C.c_void_p(stream))
+            mask = self._mask(hops)
+            ld_row, ld_hop = (grad.stride(0) if self.n_rows > 0 else h_sel * d), grad.stride(1)
+            # scratch: slice-major copy of the stacked gradient (same rules as the forward launch)
+            ws_bytes = int(L.h2gcn_spmm_workspace_bytes(self._handle, mask, 1, C.c_void_p(grad.data_ptr()), ld_row, ld_hop, d)) if self.use_workspace else 0
+            opts = None
+            if ws_bytes:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+                opts = _capi.LaunchOpts(struct_size=C.sizeof(_capi.LaunchOpts), flags=0, workspace=ws.data_ptr(),
+                                        workspace_bytes=ws_bytes, bias=None)
+            st = L.h2gcn_spmm_hops_T_opts_f32(self._handle, mask, C.c_void_p(grad.data_ptr()), ld_row, ld_hop, d,
+                                              C.c_void_p(dx.data_ptr()), dx.stride(0),
+                                              C.byref(opts) if opts is not None else None, C.c_void_p(stream))
         _capi.check(st)
         return dx
 

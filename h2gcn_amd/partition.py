@@ -5,9 +5,11 @@ Scheme: rank p owns a contiguous block of rows of every hop mat
 column ids) and the matching rows of the embedding ``X[rows_p, :]``.  ``Y[i, k, :]`` depends only on row ``i`` of
 ``A_k`` and on the rows of ``X`` its column ids name, so one exchange per layer suffices: all-gather ``X`` (RCCL
 ``ncclAllGather`` over xGMI through ``torch.distributed``, backend "nccl"), then the local fused SpMM.  The
-per-row summation order depends on the row's own nonzeros and on the kernel's slice width, never on the partitioning,
-so P ranks reproduce the 1-rank result bit-for-bit when both use the same feature-chunk widths.  Everything after the aggregation in H2GCN (concat, dropout, classifier) is row-local; the backward
-pass needs the mirror-image reduce-scatter of ``dX``.
+per-row summation tree is canonical (``include/h2gcn_hip.h``, "Floating point"): it depends on the row's own nonzeros
+only, never on the partitioning, the slice width or the feature chunking, so P ranks reproduce the 1-rank result
+bit-for-bit whatever schedule either side picked (feature chunks are kept >= 64 columns wide for that reason).
+Everything after the aggregation in H2GCN (concat, dropout, classifier) is row-local; the backward pass needs the
+mirror-image reduce-scatter of ``dX``.
 
 Rows are split into equal blocks (``ceil(N/P)`` rows, last block shorter or empty) so that the all-gather is a
 single fixed-count collective; the gathered buffer is padded to ``P * ceil(N/P)`` rows and viewed as ``[:N]``.
@@ -218,10 +220,11 @@ class PipelinedHopAggregation:
 
     The embedding is exchanged in ``n_chunks`` feature-column chunks on a side stream; the fused 1+2-hop SpMM of
     chunk ``c`` (main stream) runs while chunk ``c+1`` is still in flight over xGMI.  Output columns are
-    independent sums; a P-rank run equals the 1-rank run WITH THE SAME CHUNK WIDTHS bit-for-bit (the per-row summation
-    tree depends on the slice width the kernel derives from the chunk width, never on the partition); different chunk
-    widths agree to rounding (~1e-7), not bitwise.  Costs: the column ids / values are re-read once per chunk (8 B per edge against ``4*d/C`` B
-    of gathered features) and the local shard is staged once into chunk-major send buffers.
+    independent sums and the kernel's per-row summation tree is the same for every chunk width >= 64 columns, so a
+    P-rank run equals the 1-rank run bit-for-bit WHATEVER chunking either of them uses (chunks narrower than 64 columns
+    would run on the narrow-slice kernels, which have their own tree: refused for HIP plans).  Costs: the column ids /
+    values are re-read once per chunk (8 B per edge against ``4*d/C`` B of gathered features) and the local shard is
+    staged once into chunk-major send buffers.
 
     xGMI arithmetic: at P ranks each GPU receives ``(P-1)/P * N * d * 4`` bytes per layer over
     ``P-1`` point-to-point links; on the products shape that is of the same order as the per-rank SpMM time,
@@ -248,6 +251,10 @@ class PipelinedHopAggregation:
             if d % int(n_chunks) != 0:
                 raise ValueError(f"d = {d} is not divisible into {n_chunks} chunks")
             widths = [d // int(n_chunks)] * int(n_chunks)
+        min_cols = int(getattr(plan, "min_chunk_cols", 1))
+        if len(widths) > 1 and min(widths) < min_cols:
+            raise ValueError(f"feature chunks {widths}: chunks narrower than {min_cols} columns would leave the canonical "
+                             "summation tree (results would depend on the chunking)")
         self.widths = widths
         self.offsets = [sum(widths[:c]) for c in range(len(widths))]
         self.plan = plan
@@ -484,7 +491,7 @@ class ShardedHops:
     ``layer(sharded_hops, x_local) -> [n_local, H, d]`` all-gathers ``x_local`` (feature-chunk pipelined) and
     aggregates; its backward is the shard adjoint followed by a reduce-scatter."""
 
-    def __init__(self, plan, n_global: int, device, group: Optional[dist.ProcessGroup] = None, chunk_cols: int = 32,
+    def __init__(self, plan, n_global: int, device, group: Optional[dist.ProcessGroup] = None, chunk_cols: int = 64,
                  max_chunks: int = 4, exchange: Optional[str] = None):
         #: "allgather" (RCCL) | "p2p" | "ipc_engine" | "ipc_kernel"; default from $H2GCN_EXCHANGE, else "allgather"
         self.exchange = exchange or os.environ.get("H2GCN_EXCHANGE", "allgather")

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define H2GCN_ABI_VERSION 2
+#define H2GCN_ABI_VERSION 3
 #define H2GCN_MAX_HOPS 8
 
 typedef enum h2gcn_status {
@@ -76,7 +76,9 @@ typedef struct h2gcn_plan_opts {
                                     scratch copy (A/B measurements); 5 = force the short-row mode.  Variants
                                     0, 2, 3, 4, 5 give identical bits.                                          */
     int32_t slice_cols;          /* feature columns per slice of the slice-major schedule: 16/32/64/128/256,
-                                    0 = heuristic (narrower slices when X is far beyond the Infinity Cache)  */
+                                    0 = heuristic (narrower slices when X is far beyond the Infinity Cache).
+                                    64, 128 and 256 give identical bits (one canonical summation tree); 16 and
+                                    32 -- picked by the heuristic only for d < 64 -- have their own tree          */
     int32_t reserved[2];
 } h2gcn_plan_opts;
 
@@ -132,11 +134,12 @@ int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t*
                     int64_t* n_long_segments, int32_t* has_transpose);
 
 /* The schedule a launch of this plan would use for feature width d and source row stride ld_src (reports, tests):
- * columns per slice of the slice-major schedule, number of slices, segment walk (0 = wave per
- * segment, 1 = the same with index prefetch across segments, 2 = short-row mode: one lane group per segment), whether a forward launch with scratch would gather from a slice-major copy.  adjoint != 0 asks about
- * h2gcn_spmm_hops_T_f32 (ld_src = ldg_row).  Any out pointer may be NULL. */
+ * columns per slice of the slice-major schedule, number of slices, segment walk (0 = wave per segment, 1 = the same
+ * with index prefetch across segments, 2 = short-row mode: one lane group per segment), whether a launch that is given
+ * scratch would gather from a slice-major copy.  adjoint != 0 asks about h2gcn_spmm_hops_T_f32 (ld_src = ldg_row,
+ * hop stride d).  16-byte aligned base pointers are assumed.  Any out pointer may be NULL. */
 int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, int64_t ld_src, int32_t d,
-                        int32_t* slice_cols, int32_t* n_slices, int32_t* index_prefetch, int32_t* scratch_copy);
+                        int32_t* slice_cols, int32_t* n_slices, int32_t* segment_walk, int32_t* scratch_copy);
 
 /*
  * Fused multi-hop aggregation, forward:
@@ -154,9 +157,17 @@ int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint
  *
  *   X_dev   fp32, n_cols rows of d values, row stride ldx >= d (elements)
  *   Y_dev   fp32, must not alias X
- *   d       feature width >= 1.  Fast paths: d a multiple of 16 with 16-byte aligned X/Y and strides that are
- *           multiples of 4 (processed in column slices of 16..256); anything else takes the generic column-tiled
- *           path (same results).
+ *   d       feature width >= 1, any value (the reference accepts any b.shape[1], _layers.py:62-76).  16-byte
+ *           addressable X with d % 4 == 0 is gathered in place by the float4 kernels (column slices of 16..256); any
+ *           other width / alignment runs on the same kernels through the zero-padded scratch copy when the launch is
+ *           given scratch (h2gcn_spmm_hops_opts_f32), else on the generic column-tiled kernel.
+ *
+ * Floating point: fp32 multiply-add per nonzero in ONE canonical summation tree per output element -- neighbour j of
+ * the row (ascending column order, the reference's order after tf.sparse.reorder, _dataset.py:535) is added into
+ * partial P[j mod 4], the element is (P0 + P1) + (P2 + P3) -- for every kernel, slice width >= 64, feature chunking,
+ * scratch copy and segment walk (rows with >= long_row_threshold nonzeros: the same tree per wave over the wave's
+ * 64-neighbour chunks, wave totals added in order).  The bits of Y depend only on the row's nonzeros, X and
+ * long_row_threshold: a row-partitioned multi-GPU run equals the single-GPU run bit-for-bit.
  */
 int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X_dev, int64_t ldx,
                         int32_t d, float* Y_dev, int64_t ldy_row, int64_t ldy_hop, void* stream);
@@ -164,18 +175,24 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
 /*
  * Same launch with options.
  *
- * workspace / workspace_bytes: caller-provided scratch.  When the row stride of X is a multiple of 1 KiB (e.g. a
- *   contiguous [N, 256] embedding) and the operand is far beyond the caches, gathering column slices straight out
- *   of X wastes three quarters of the cache sets; the launch then first copies X into a slice-major layout inside
- *   the scratch (one streaming pass, ~3 % of the launch) and gathers from there.  h2gcn_spmm_workspace_bytes() says
- *   how much scratch such a launch wants (0 = the plain launch is already the fastest); NULL / too small simply
- *   selects the plain launch.  The same copy is used when the rows of X are not cache-line aligned (ldx*4 not a
- *   multiple of 128, e.g. d = 100, 200): its 64-column blocks are.  Results: bit-identical to the plain launch in
- *   the 1-KiB-stride case (same slice width); equal to rounding in the unaligned case (different slice width).  The scratch is only used by this launch (on
- *   `stream`); launches that may run concurrently need separate scratch.
+ * workspace / workspace_bytes: caller-provided scratch for a slice-major copy of the gather source (one streaming pass,
+ *   a few % of the launch), from which the launch then gathers.  h2gcn_spmm_workspace_bytes() says how much scratch a
+ *   launch wants (0 = the plain launch is already the fastest); NULL / too small simply selects the plain launch.
+ *   The copy is used (a) when the row stride of X is a multiple of 1 KiB (e.g. a contiguous [N, 256] embedding) and
+ *   the operand is far beyond the caches: gathering column slices straight out of such rows wastes three quarters of
+ *   the cache sets; (b) when the rows are wide and not cache-line aligned (ld*4 not a multiple of 128, d > 128): the
+ *   copy's 64-column blocks are; (c) when d % 4 != 0 or the source is not 16-byte addressable (raw feature widths:
+ *   Cora 1433, citeseer 3703): the copy is zero-padded to whole blocks, so the float4 gather kernels serve the launch
+ *   instead of the generic column-tiled kernel.  Results are bit-identical with and without scratch (canonical
+ *   summation tree).  The scratch is only used by this launch (on `stream`); launches that may run concurrently need
+ *   separate scratch.
  * bias / H2GCN_LAUNCH_RELU: fused epilogue of the store, Y = act(A X + bias[c]) -- what SparseDense.call applies
  *   after its sparse product (reference h2gcn/models/_layers.py:45-52: `+ self.bias`, then `self.activation`), so
- *   that the feature embedding needs no second pass over its output.  bias: d floats (device) or NULL.
+ *   that the feature embedding needs no second pass over its output.  bias: d floats (device) or NULL.  Forward only.
+ *
+ * h2gcn_spmm_workspace_bytes: adjoint != 0 asks about h2gcn_spmm_hops_T_opts_f32; src_dev / ld_src / ld_src_hop
+ *   describe the gather source of that launch (forward: X_dev, ldx, 0; adjoint: dY_dev, ldg_row, ldg_hop) -- the
+ *   pointer is only inspected for its alignment, never dereferenced.
  */
 #define H2GCN_LAUNCH_RELU 0x1u
 typedef struct h2gcn_launch_opts {
@@ -185,7 +202,8 @@ typedef struct h2gcn_launch_opts {
     size_t workspace_bytes;
     const float* bias_dev;     /* d floats or NULL                                                           */
 } h2gcn_launch_opts;
-size_t h2gcn_spmm_workspace_bytes(const h2gcn_plan_t* plan, uint32_t hop_mask, int64_t ldx, int32_t d);
+size_t h2gcn_spmm_workspace_bytes(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, const float* src_dev,
+                                  int64_t ld_src, int64_t ld_src_hop, int32_t d);
 int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X_dev, int64_t ldx,
                              int32_t d, float* Y_dev, int64_t ldy_row, int64_t ldy_hop,
                              const h2gcn_launch_opts* opts, void* stream);
@@ -203,6 +221,12 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
  */
 int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* dY_dev, int64_t ldg_row,
                           int64_t ldg_hop, int32_t d, float* dX_dev, int64_t ldx, void* stream);
+/* The adjoint with options: only workspace_dev / workspace_bytes are used (bias_dev and flags must be 0).  With
+ * scratch the stacked gradient is copied slice-major per hop when its rows are wide and not cache-line aligned, or
+ * when d % 4 != 0 / dY is not 16-byte addressable -- same rules, same bits as the forward launch. */
+int h2gcn_spmm_hops_T_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* dY_dev, int64_t ldg_row,
+                               int64_t ldg_hop, int32_t d, float* dX_dev, int64_t ldx,
+                               const h2gcn_launch_opts* opts, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Operand construction on the device: exact-k-hop neighbourhood rings and their normalisation -- the step that

@@ -127,3 +127,36 @@ def rows_subset(hops, x, rows, dtype=np.float64):
                 acc = acc + dtype(da[t]) * x[ix[t]].astype(dtype)
             out[r, k] = acc
     return out
+
+
+def gcn_layer_tree(hops, x, long_threshold=256):
+    """Kernel-order restatement (see ``oracle_spmm_tree_f32``): the library's documented canonical summation tree,
+    bit-exact target for every HIP kernel variant.  [N_rows, H, d] float32."""
+    parts = [_csr_parts(m) for m in hops]
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n_rows, d, H = len(parts[0][0]) - 1, x.shape[1], len(parts)
+    y = np.zeros((n_rows, H, d), dtype=np.float32)
+    _lib().oracle_spmm_tree_f32(C.c_int(H), C.c_int64(n_rows), _ptr_array([p[0] for p in parts], None),
+                                _ptr_array([p[1] for p in parts], None), _ptr_array([p[2] for p in parts], None),
+                                x.ctypes.data_as(C.c_void_p), C.c_int64(d), C.c_int64(0), C.c_int64(d),
+                                C.c_int(long_threshold), C.c_int(0), y.ctypes.data_as(C.c_void_p), C.c_int64(H * d), C.c_int64(d))
+    return y
+
+
+def gcn_layer_grad_tree(hops, dy, n_cols, long_threshold=256):
+    """Adjoint in the library's documented order: the transposed operands (stable: ascending row order inside each
+    output row), partials running on across the hops.  [n_cols, d] float32."""
+    dy = np.ascontiguousarray(dy, dtype=np.float32)
+    n_rows, H, d = dy.shape
+    parts = []
+    for m in hops:
+        ip, ix, da = _csr_parts(m)
+        t = sp.csr_matrix((da, ix, ip), shape=(n_rows, n_cols)).T.tocsr()  # csr -> csc view -> csr: stable counting sort
+        t.sort_indices()
+        parts.append(_csr_parts(t))
+    dx = np.zeros((n_cols, d), dtype=np.float32)
+    _lib().oracle_spmm_tree_f32(C.c_int(H), C.c_int64(n_cols), _ptr_array([p[0] for p in parts], None),
+                                _ptr_array([p[1] for p in parts], None), _ptr_array([p[2] for p in parts], None),
+                                dy.ctypes.data_as(C.c_void_p), C.c_int64(H * d), C.c_int64(d), C.c_int64(d),
+                                C.c_int(long_threshold), C.c_int(1), dx.ctypes.data_as(C.c_void_p), C.c_int64(d), C.c_int64(0))
+    return dx

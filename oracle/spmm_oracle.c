@@ -129,3 +129,81 @@ void oracle_gcn_layer_grad_f32(int n_hops, int64_t n_rows, int64_t n_cols, const
     }
     free(tmp);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Kernel-order restatement (TEST INFRASTRUCTURE, like everything in this file).  The reference's arithmetic per
+ * output element is a plain sequential fp32 sum in ascending column order (above).  The HIP library documents ONE
+ * canonical regrouping of exactly those terms (include/h2gcn_hip.h, "Floating point"): neighbour j of the row goes,
+ * with one fused multiply-add, into partial P[j mod 4]; the element is (P0 + P1) + (P2 + P3); a segment with >=
+ * long_threshold nonzeros is cut into 64-neighbour chunks dealt round-robin to 4 "waves", each wave builds that tree
+ * over its chunks, and the 4 wave totals are added in order.  These functions restate that documented order on the
+ * CPU so that tests can demand BIT-EXACT agreement of every kernel variant / slice width / feature chunking / row
+ * partition with one fixed function of the inputs -- which is how SURVEY.md 8(e)'s "P-GPU == 1-GPU bit for bit" is
+ * pinned.  They are not a second reference: parity with the reference's order is what the 1e-5 tests above check.
+ */
+static void tree_chunks(const int32_t* ci, const float* va, int64_t sb, int64_t se, int chunk0, int chunk_step,
+                        const float* src, int64_t ld, int64_t d, float* P /* [4][d] */) {
+    for (int64_t base = sb + (int64_t)chunk0 * 64; base < se; base += (int64_t)chunk_step * 64) {
+        const int64_t n = se - base < 64 ? se - base : 64;
+        for (int64_t jj = 0; jj < n; ++jj) {
+            float* p = P + (jj & 3) * d;
+            const float a = va[base + jj];
+            const float* row = src + (int64_t)ci[base + jj] * ld;
+            for (int64_t c = 0; c < d; ++c) p[c] = fmaf(a, row[c], p[c]);
+        }
+    }
+}
+
+static void tree_fold(const float* P, int64_t d, float* out) {
+    for (int64_t c = 0; c < d; ++c) out[c] = (P[c] + P[d + c]) + (P[2 * d + c] + P[3 * d + c]);
+}
+
+/* mode_sum == 0: Y[i, s, :] per hop (forward, y row stride ldy_row, hop stride ldy_hop);
+ * mode_sum == 1: out[i, :] = sum over the hops of A_s[i, :] @ src[:, s, :] (adjoint on transposed operands: src row
+ *                stride ld_src, hop stride ld_src_hop; the partials run on across the hops). */
+void oracle_spmm_tree_f32(int n_hops, int64_t n_rows, const int64_t* const* rowptr, const int32_t* const* colidx,
+                          const float* const* vals, const float* src, int64_t ld_src, int64_t ld_src_hop, int64_t d,
+                          int long_threshold, int mode_sum, float* y, int64_t ldy_row, int64_t ldy_hop) {
+    float* P = (float*)malloc((size_t)4 * d * sizeof(float));
+    float* T = (float*)malloc((size_t)4 * d * sizeof(float));
+    for (int64_t i = 0; i < n_rows; ++i) {
+        if (!mode_sum) {
+            for (int s = 0; s < n_hops; ++s) {
+                const int64_t sb = rowptr[s][i], se = rowptr[s][i + 1];
+                float* o = y + i * ldy_row + s * ldy_hop;
+                if (se - sb >= long_threshold) {
+                    for (int w = 0; w < 4; ++w) {
+                        memset(P, 0, (size_t)4 * d * sizeof(float));
+                        tree_chunks(colidx[s], vals[s], sb, se, w, 4, src, ld_src, d, P);
+                        tree_fold(P, d, T + w * d);
+                    }
+                    for (int64_t c = 0; c < d; ++c) o[c] = ((T[c] + T[d + c]) + T[2 * d + c]) + T[3 * d + c];
+                } else {
+                    memset(P, 0, (size_t)4 * d * sizeof(float));
+                    tree_chunks(colidx[s], vals[s], sb, se, 0, 1, src, ld_src, d, P);
+                    tree_fold(P, d, o);
+                }
+            }
+        } else {
+            int is_long = 0;
+            for (int s = 0; s < n_hops; ++s) is_long |= (rowptr[s][i + 1] - rowptr[s][i] >= long_threshold);
+            float* o = y + i * ldy_row;
+            if (is_long) {
+                for (int w = 0; w < 4; ++w) {
+                    memset(P, 0, (size_t)4 * d * sizeof(float));
+                    for (int s = 0; s < n_hops; ++s)
+                        tree_chunks(colidx[s], vals[s], rowptr[s][i], rowptr[s][i + 1], w, 4, src + s * ld_src_hop, ld_src, d, P);
+                    tree_fold(P, d, T + w * d);
+                }
+                for (int64_t c = 0; c < d; ++c) o[c] = ((T[c] + T[d + c]) + T[2 * d + c]) + T[3 * d + c];
+            } else {
+                memset(P, 0, (size_t)4 * d * sizeof(float));
+                for (int s = 0; s < n_hops; ++s)
+                    tree_chunks(colidx[s], vals[s], rowptr[s][i], rowptr[s][i + 1], 0, 1, src + s * ld_src_hop, ld_src, d, P);
+                tree_fold(P, d, o);
+            }
+        }
+    }
+    free(P);
+    free(T);
+}

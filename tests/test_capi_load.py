@@ -55,7 +55,7 @@ def test_null_plan_is_an_error_not_a_crash():
     assert L.h2gcn_spmm_hops_opts_f32(None, 0, None, 0, 1, None, 0, 0, None, None) == _capi.ERR_INVALID_ARGUMENT
     assert L.h2gcn_plan_schedule(None, 0, 0, 1, 1, None, None, None, None) == _capi.ERR_INVALID_ARGUMENT
     assert L.h2gcn_plan_set_values(None, 0, None, None) == _capi.ERR_INVALID_ARGUMENT
-    assert L.h2gcn_spmm_workspace_bytes(None, 0, 1, 1) == 0
+    assert L.h2gcn_spmm_workspace_bytes(None, 0, 0, None, 1, 0, 1) == 0
     assert L.h2gcn_ring_count(-1, None, None, None, None, 0, None, None, 0, 0, None, None, 0, None, None, None, 0, None) == _capi.ERR_INVALID_ARGUMENT
     assert L.h2gcn_hop_normalize(4, None, None, 1, None, 0, None, None) == _capi.ERR_INVALID_ARGUMENT
     assert L.h2gcn_xchg_status(None) == _capi.ERR_INVALID_ARGUMENT and L.h2gcn_xchg_allgather_end(None, 0, None) == _capi.ERR_INVALID_ARGUMENT

@@ -57,8 +57,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("exchange,chunks", [("allgather", 1), ("allgather", 4), ("ipc_engine", 1), ("ipc_engine", 4),
-                                             ("ipc_kernel", 1), ("ipc_kernel", 4)])
+@pytest.mark.parametrize("exchange,chunks", [("allgather", 1), ("allgather", 2), ("ipc_engine", 1), ("ipc_engine", 2),
+                                             ("ipc_kernel", 1), ("ipc_kernel", 2)])
 def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, exchange, chunks):
     from h2gcn_amd import HopPlan, synth
     from h2gcn_amd.partition import PipelinedHopAggregation
@@ -71,14 +71,15 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, exchange, chunks):
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    # single-process answer with the same schedule (same chunking -> same kernels -> same bits)
+    # single-process answer from ONE plain launch: the canonical summation tree makes the chunking invisible
     dev = torch.device("cuda:0")
     n, d = 30000, 128
     degs = [synth.synth_degrees(n, 40 * n, s, n) for s in (1, 2)]
     csr = [synth.synth_hop_rows(degs[k], n, (1, 2)[k], 0, n, dev) for k in range(2)]
     plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n, build_transpose=True)
     x = synth.synth_features(d, 3, 0, n, dev)
-    y = PipelinedHopAggregation(plan, n, d, chunks, dev)(x)
+    y = plan.spmm(x)
+    assert torch.equal(y, PipelinedHopAggregation(plan, n, d, 2, dev)(x))
     w = synth.synth_features(2 * d, 9, 0, n, dev).view(n, 2, d)
     dx = plan.spmm_t(w)
     y2 = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(2)], 0)
@@ -271,11 +272,20 @@ def _run_bench(world, extra, tmp_path, env_extra=None):
     return json.loads(lines[0])
 
 
+def _keep(name, line):
+    """Tests never write into the repository; set H2GCN_TEST_ARTIFACTS=<dir> to keep the bench lines they produce."""
+    d = os.environ.get("H2GCN_TEST_ARTIFACTS")
+    if d:
+        Path(d).mkdir(parents=True, exist_ok=True)
+        (Path(d) / name).write_text(json.dumps(line))
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_bench_multi_rank_branch_runs_and_matches_one_rank(tmp_path, world):
     """bench.py's N > 1 branch end to end (calibration over every exchange x chunking, diagnostics, timed steps,
-    JSON line) on the arxiv shape, N ranks sharing the box's GPU; the N-rank result has the same bits as the 1-rank
-    result with the same chunking (order-independent checksum of Y)."""
+    JSON line) on the arxiv shape, N ranks sharing the box's GPU; the N-rank result -- whatever chunking the calibration
+    picked -- has the same bits as the default 1-rank line (one launch) AND as 1-rank runs with other chunkings / slice
+    widths (order-independent checksum of Y): the canonical summation tree, SURVEY.md 8(e) "Determinism"."""
     # (N = 4: the gloo stand-in for the grouped send/recv exchange takes ~3 s per step on a shared GPU -- left to N = 2)
     extra_env = {"H2GCN_BENCH_EXCHANGES": "allgather,ipc_engine,ipc_kernel"} if world == 4 else None
     out = _run_bench(world, ["--shape", "arxiv", "--steps", "3", "--warmup", "1"], tmp_path, env_extra=extra_env)
@@ -287,12 +297,14 @@ def test_bench_multi_rank_branch_runs_and_matches_one_rank(tmp_path, world):
         assert any(k.startswith(ex + "/") for k in cal), (cal, diag["rejected"])
     assert diag["exchange_only_ms"] > 0 and diag["spmm_only_ms"] > 0
     (tmp_path / f"line{world}.json").write_text(json.dumps(out))
-    prof = ROOT / "gpurun_out"
-    prof.mkdir(exist_ok=True)
-    (prof / f"bench_shared_gpu_arxiv_n{world}.json").write_text(json.dumps(out))
-    one = _run_bench(1, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--chunks", str(out["config"]["feature_chunks"])], tmp_path)
+    _keep(f"bench_shared_gpu_arxiv_n{world}.json", out)
+    one = _run_bench(1, ["--shape", "arxiv", "--steps", "2", "--warmup", "1"], tmp_path)
     assert one["config"]["y_checksum"] == out["config"]["y_checksum"]
     assert one["config"]["nnz_per_hop"] == out["config"]["nnz_per_hop"]
+    if world == 2:
+        for extra in (["--chunks", "2"], ["--chunks", "64+64"], ["--slice-cols", "64"], ["--slice-cols", "128"], ["--slice-cols", "256"]):
+            alt = _run_bench(1, ["--shape", "arxiv", "--steps", "1", "--warmup", "1", "--no-adjoint"] + extra, tmp_path)
+            assert alt["config"]["y_checksum"] == out["config"]["y_checksum"], extra
 
 
 def test_bench_two_ranks_products_shape(tmp_path):
@@ -303,7 +315,7 @@ def test_bench_two_ranks_products_shape(tmp_path):
         out = _run_bench(2, ["--steps", "2", "--warmup", "1", "--exchange", ex, "--chunks", "2", "--no-adjoint"], tmp_path)
         assert out["value"] > 0 and out["config"]["diagnostics"]["exchange"] == ex
         sums[ex] = out["config"]["y_checksum"]
-        (ROOT / "gpurun_out" / f"bench_shared_gpu_products_n2_{ex}.json").write_text(json.dumps(out))
+        _keep(f"bench_shared_gpu_products_n2_{ex}.json", out)
     assert sums["allgather"] == sums["ipc_engine"]
 
 
@@ -329,6 +341,6 @@ def test_bench_eight_ranks_on_one_gpu(tmp_path):
     assert out["n_gpus"] == 8 and out["value"] > 0
     cal = out["config"]["diagnostics"]["calibration_ms_per_step"]
     assert set(cal) == {"allgather/2", "ipc_kernel/2"}, (cal, out["config"]["diagnostics"]["rejected"])
-    (ROOT / "gpurun_out" / "bench_shared_gpu_arxiv_n8.json").write_text(json.dumps(out))
-    one = _run_bench(1, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--chunks", "2", "--no-adjoint"], tmp_path)
+    _keep("bench_shared_gpu_arxiv_n8.json", out)
+    one = _run_bench(1, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--no-adjoint"], tmp_path)
     assert one["config"]["y_checksum"] == out["config"]["y_checksum"]

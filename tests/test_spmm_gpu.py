@@ -2,8 +2,10 @@
 
 Tolerance: BASELINE.json's north star asks for layer outputs within 1e-5 of the reference in fp32.  ATOL below
 is that 1e-5 (absolute, on outputs whose magnitude is O(1) or smaller); the only arithmetic difference between
-the kernel and the oracle's sequential loop is the association order of the per-row sum (2-4 interleaved lane
-groups, 4 waves for long rows) and fused multiply-add.
+the kernel and the oracle's sequential loop is the association order of the per-row sum (the library's documented
+canonical tree: 4 interleaved partials, 4 waves for long rows) and fused multiply-add.  That tree is restated in the
+oracle (``og.gcn_layer_tree``), so every kernel variant / slice width / feature chunking is ALSO required to match one
+fixed function of the inputs bit for bit (``test_bits_are_the_canonical_tree_*``).
 """
 import numpy as np
 import pytest
@@ -171,9 +173,10 @@ def test_slice_major_scratch_copy_is_bitwise_identical():
     plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n, slice_cols=64)
     x = synth.synth_features(d, 7, 0, n, device)
     L = _capi.lib()
-    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, d, d) == n * d * 4          # contiguous: 1 KiB stride
-    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, d + 32, d) == 0             # padded rows do not alias
-    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 64, 64) == 0
+    xp = C.c_void_p(x.data_ptr())
+    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 0, xp, d, 0, d) == n * d * 4          # contiguous: 1 KiB stride
+    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 0, xp, d + 32, 0, d) == 0             # padded rows do not alias
+    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 0, xp, 64, 0, 64) == 0
     y_ws = plan.spmm(x)
     plan.use_workspace = False
     y_plain = plan.spmm(x)
@@ -198,7 +201,10 @@ def test_slice_major_scratch_copy_is_bitwise_identical():
 def test_scratch_copy_for_rows_that_are_not_line_aligned():
     """d = 200 (`--hidden 100`, second round): rows of 800 B are only 16-B aligned.  With scratch the launch gathers
     from line-aligned 64-column blocks (slices 64, 64, 64, 8 -- the last one masked); results equal the plain launch
-    (one masked slice of 256) to rounding and the oracle on sampled rows; guard columns of a strided output untouched."""
+    (one masked slice of 256) BIT FOR BIT (canonical summation tree) and the oracle on sampled rows; guard columns of a
+    strided output untouched."""
+    import ctypes as C
+
     from h2gcn_amd import HopPlan, _capi, synth
 
     n, d, device = 700_000, 200, dev()
@@ -207,8 +213,9 @@ def test_scratch_copy_for_rows_that_are_not_line_aligned():
     plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n)
     x = synth.synth_features(d, 17, 0, n, device)
     L = _capi.lib()
-    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, d, d) == n * 4 * 64 * 4      # 4 blocks of 64 columns
-    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 224, d) == 0                 # rows padded to 896 B: aligned
+    xp = C.c_void_p(x.data_ptr())
+    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 0, xp, d, 0, d) == n * 4 * 64 * 4      # 4 blocks of 64 columns
+    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 0, xp, 224, 0, d) == 0                 # rows padded to 896 B: aligned
     sched = plan.schedule(d)
     assert sched["scratch_copy"] and sched["slice_cols"] == 64 and sched["n_slices"] == 4
     ybuf = torch.full((n, 2, d + 8), 3.0, device=device)
@@ -216,7 +223,7 @@ def test_scratch_copy_for_rows_that_are_not_line_aligned():
     assert bool((ybuf[:, :, d:] == 3.0).all())
     plan.use_workspace = False
     y_plain = plan.spmm(x)
-    assert (y_ws - y_plain).abs().max().item() <= 2e-6
+    assert torch.equal(y_ws, y_plain)
     for r0 in (0, 4321, n - 8):
         parts = [synth.synth_hop_rows_np(degs[k], n, (15, 16)[k], r0, r0 + 8) for k in range(2)]
         cols = np.unique(np.concatenate([q[1] for q in parts]))
@@ -402,21 +409,76 @@ def test_rows_per_wave_does_not_change_results(rpw):
     assert np.array_equal(y0, y1)  # geometry never changes the arithmetic
 
 
-@pytest.mark.parametrize("d", [128, 256])
+@pytest.mark.parametrize("d", [128, 256, 200])
 def test_column_slices_do_not_change_results(d):
     """The slice-major schedule (Infinity-Cache-sized column slices inside one launch) re-orders independent output
-    columns; different slice widths use different lane-group counts, so results agree to rounding (not bitwise),
-    while a fixed width is bitwise repeatable."""
+    columns.  Slice widths 64 / 128 / 256 have different lane geometries (4 / 2 / 1 gathered rows per load) but build
+    the SAME canonical summation tree: bitwise equal results, equal to the oracle's restatement of that tree.  The
+    narrow slices (16 / 32, chosen by the heuristic only for d < 64) agree to rounding."""
     hops = [rand_csr(900, 900, 0.05, 1, empty_frac=0.1), rand_csr(900, 900, 0.1, 2)]
     hops[1] = sp.csr_matrix(sp.vstack([hops[1][:3], sp.csr_matrix(np.full((1, 900), 0.01, dtype=np.float32)), hops[1][4:]]))
     x = np.random.default_rng(1).uniform(-1, 1, (900, d)).astype(np.float32)
-    ref, _ = run_hip(hops, x, slice_cols=d, long_row_threshold=512)
-    assert_close(ref, hops, x)
-    for sc in (16, 32, 64, 128, 0):
+    tree = og.gcn_layer_tree(hops, x, long_threshold=512)
+    assert_close(tree, hops, x)
+    for sc in (0, 64, 128, 256):
+        for rpw in (0, 2):
+            y, plan = run_hip(hops, x, slice_cols=sc, long_row_threshold=512, rows_per_wave=rpw)
+            assert np.array_equal(y, tree), (sc, rpw, plan.schedule(d))
+    for sc in (16, 32):
         y, _ = run_hip(hops, x, slice_cols=sc, long_row_threshold=512)
         assert_close(y, hops, x)
         y2, _ = run_hip(hops, x, slice_cols=sc, long_row_threshold=512, rows_per_wave=2)
         assert np.array_equal(y, y2), sc
+
+
+@pytest.mark.parametrize("d", [64, 100, 128, 133, 192, 256, 7, 1])
+@pytest.mark.parametrize("thr", [0, 20, 100])
+def test_bits_are_the_canonical_tree_for_every_schedule(d, thr):
+    """SURVEY.md 8(e) "Determinism": the bits of Y must not depend on how the work was scheduled.  Every segment walk
+    (variants 0 / 2 / 3 / 5), every slice width >= 64, launches with and without scratch (incl. the zero-padded copy of
+    odd widths and the generic column-tiled kernel), FEATURE CHUNKS of different widths, row blocks, hop selections and
+    the adjoint all reproduce ONE function of the inputs: the canonical tree restated in oracle/spmm_oracle.c."""
+    from h2gcn_amd import HopPlan
+
+    rng = np.random.default_rng(d * 7 + thr)
+    n = 1500
+    hops = []
+    for k in range(2):
+        deg = np.minimum(rng.poisson(5 * (2 * k + 1), n), n)
+        deg[rng.random(n) < 0.1] = 0
+        deg[rng.integers(0, n, 4)] = [70, 300, 129, 1000]
+        rows = np.repeat(np.arange(n), deg)
+        cols = np.concatenate([rng.choice(n, kk, replace=False) for kk in deg])
+        m = sp.csr_matrix((rng.uniform(-1, 1, len(rows)).astype(np.float32), (rows, cols)), shape=(n, n))
+        m.sort_indices()
+        hops.append(m)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    w = rng.uniform(-1, 1, (n, 2, d)).astype(np.float32)
+    thr_eff = thr if thr else 256
+    tree = og.gcn_layer_tree(hops, x, long_threshold=thr_eff)
+    tree_t = og.gcn_layer_grad_tree(hops, w, n, long_threshold=thr_eff)
+    assert_close(tree, hops, x)
+    xt, wt = torch.from_numpy(x).to(dev()), torch.from_numpy(w).to(dev())
+    for variant in (0, 2, 3, 5):
+        for sc in (0, 64, 128, 256):
+            plan = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr, variant=variant, slice_cols=sc)
+            for use_ws in (True, False):
+                plan.use_workspace = use_ws
+                assert np.array_equal(plan.spmm(xt).cpu().numpy(), tree), (variant, sc, use_ws, plan.schedule(d))
+                assert np.array_equal(plan.spmm_t(wt).cpu().numpy(), tree_t), (variant, sc, use_ws, "adjoint")
+            assert np.array_equal(plan.spmm(xt, hops=[1]).cpu().numpy(), tree[:, 1:]), (variant, sc)
+    plan = HopPlan.from_scipy(hops, dev(), long_row_threshold=thr)
+    if d >= 128:   # feature chunks of unequal widths (what the multi-GPU pipeline does), written into one output
+        for widths in ([64, d - 64], [d - 64, 64], [d // 2, d - d // 2]):
+            y = torch.empty((n, 2, d), device=dev())
+            c0 = 0
+            for wd in widths:
+                plan.spmm(xt[:, c0:c0 + wd], out=y[:, :, c0:c0 + wd])
+                c0 += wd
+            assert np.array_equal(y.cpu().numpy(), tree), widths
+    # a row block (what a rank of the row partition computes) gives the same rows
+    sub = HopPlan.from_scipy([h[400:900] for h in hops], dev(), long_row_threshold=thr)
+    assert np.array_equal(sub.spmm(xt).cpu().numpy(), tree[400:900])
 
 
 @pytest.mark.parametrize("d", [64, 128, 256])
@@ -467,13 +529,13 @@ def test_short_row_mode_is_bitwise_identical(d, mean_deg):
         for rpw in (0, 1, 3, 7):
             for sc in (0, 64, 128):
                 alt = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr, variant=5, rows_per_wave=rpw, slice_cols=sc)
-                base = ref if sc == 0 else HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr, variant=3, slice_cols=sc)
+                base = ref   # one canonical tree: the plain walk at the default slice width is the target for every slice width
                 assert torch.equal(base.spmm(x), alt.spmm(x)), (thr, rpw, sc)
                 assert torch.equal(base.spmm_t(w), alt.spmm_t(w)), (thr, rpw, sc)
                 assert torch.equal(base.spmm(x, hops=[1]), alt.spmm(x, hops=[1]))
                 assert torch.equal(base.spmm_t(w[:, :1].contiguous(), hops=[0]), alt.spmm_t(w[:, :1].contiguous(), hops=[0]))
     assert_close(ref.spmm(x).cpu().numpy(), hops, x.cpu().numpy())
-    assert alt.schedule(d)["index_prefetch"] in (True, False)
+    assert alt.schedule(d)["segment_walk"].startswith(("lane group", "wave per segment"))
 
 
 def test_variant_scalar_addressing_matches():
@@ -525,21 +587,42 @@ def test_hop_selection_and_strided_output():
     assert (b[:, :64] == -7).all() and (b[:, 256:] == -7).all()
 
 
-def test_unaligned_operands_take_the_generic_path():
-    """Views whose base is not 16-byte aligned or whose row stride is odd cannot use 16-byte loads: same results
-    through the column-tiled path."""
-    from h2gcn_amd import HopPlan
+def test_unaligned_operands_and_odd_widths():
+    """Views whose base is not 16-byte aligned, odd row strides, d % 4 != 0 (raw feature widths: the reference takes any
+    b.shape[1], _layers.py:62-76): with scratch the launch gathers from the zero-padded slice-major copy on the float4
+    kernels, without it the generic column-tiled kernel runs -- same bits (canonical tree), guard columns untouched."""
+    import ctypes as C
+
+    from h2gcn_amd import HopPlan, _capi
 
     hops = [rand_csr(400, 400, 0.05, 1), rand_csr(400, 400, 0.1, 2)]
-    x = np.random.default_rng(1).uniform(-1, 1, (400, 128)).astype(np.float32)
-    want = og.gcn_layer_f64acc(hops, x)
-    plan = HopPlan.from_scipy(hops, dev())
-    xbuf = torch.zeros((400, 131), device=dev())
-    xbuf[:, 1:129] = torch.from_numpy(x).to(dev())
-    ybuf = torch.zeros((400, 259), device=dev())
-    y = plan.spmm(xbuf[:, 1:129], out=ybuf[:, 2:258].view(400, 2, 128))
-    assert np.abs(y.cpu().numpy() - want).max() <= ATOL * 4
-    assert_close(y.cpu().numpy(), hops, x)
+    hops[0] = sp.csr_matrix(sp.vstack([hops[0][:3], sp.csr_matrix(np.full((1, 400), 0.01, dtype=np.float32)), hops[0][4:]]))
+    plan = HopPlan.from_scipy(hops, dev(), build_transpose=True)
+    L = _capi.lib()
+    for d in (128, 133, 1433 // 7, 3):
+        x = np.random.default_rng(d).uniform(-1, 1, (400, d)).astype(np.float32)
+        w = np.random.default_rng(d + 1).uniform(-1, 1, (400, 2, d)).astype(np.float32)
+        tree = og.gcn_layer_tree(hops, x)
+        tree_t = og.gcn_layer_grad_tree(hops, w, 400)
+        assert_close(tree, hops, x)
+        xbuf = torch.zeros((400, d + 3), device=dev())
+        xbuf[:, 1:1 + d] = torch.from_numpy(x).to(dev())
+        xv = xbuf[:, 1:1 + d]
+        assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 0, C.c_void_p(xv.data_ptr()), d + 3, 0, d) == (400 * -(-d // 64) * 64 * 4 if d > 32 else 0)
+        wbuf = torch.zeros((400, 2 * d + 5), device=dev())
+        wv = wbuf[:, 2:2 + 2 * d].view(400, 2, d)
+        wv.copy_(torch.from_numpy(w))
+        for use_ws in (True, False):
+            plan.use_workspace = use_ws
+            ybuf = torch.full((400, 2 * d + 3), 5.0, device=dev())
+            y = plan.spmm(xv, out=ybuf[:, 2:2 + 2 * d].view(400, 2, d))
+            assert np.array_equal(y.cpu().numpy(), tree), (d, use_ws)
+            assert bool((ybuf[:, :2] == 5.0).all()) and bool((ybuf[:, 2 + 2 * d:] == 5.0).all())
+            assert np.array_equal(plan.spmm_t(wv).cpu().numpy(), tree_t), (d, use_ws)
+            # fused epilogue on the same path
+            b = torch.from_numpy(np.random.default_rng(5).uniform(-0.5, 0.5, d).astype(np.float32)).to(dev())
+            yb = plan.spmm(xv, bias=b, relu=True)
+            assert torch.equal(yb, torch.relu(torch.from_numpy(tree).to(dev()) + b)), (d, use_ws)
 
 
 def test_c_abi_from_plain_c():
