@@ -179,8 +179,9 @@ int get_long_list(const h2gcn_plan* plan, bool adjoint, uint32_t mask, const int
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Column-slice width of the EXACT kernels (float4 lanes: 16-byte addressable source with d_src % 4 == 0; n_slices =
-// ceil(d / slice), a partial last slice is masked in the kernel).
+// Column-slice width of the EXACT kernels (float4 lanes; any d >= 4, any 4-byte aligned operands: 16-byte global loads
+// and stores only need dword alignment on gfx950; n_slices = ceil(d / slice), a partial last slice is masked in the
+// kernel and the lane that straddles the end of a row whose width is not a multiple of 4 overlaps its neighbour).
 //   * d >= 64: only the widths whose lane geometry yields the canonical summation tree (64 / 128 / 256 columns, see
 //     spmm_kernels.hip.h) -- the largest one that divides d, capped so that the gather working set of one slice
 //     (n_src_rows * slice * 4 B) is friendlier to the 256 MiB Infinity Cache when the whole operand is far beyond it;
@@ -207,7 +208,13 @@ int pick_slice_cols(int d, int64_t n_src_rows, int forced, double avg_segment_nn
         if (w > 64 && avg_segment_nnz >= 16.0 && slice_bytes > 768.0 * 1024 * 1024 && d % (w / 2) == 0) continue;
         return w;
     }
-    if (d > 256) return 128;
+    if (d > 256) {
+        // many masked-at-the-end slices (raw feature widths: 1433, 3703): every slice pays one pass over the row pointers
+        // and indices, so take the widest one unless its working set is far beyond the caches on long segments
+        // (arxiv shape, d = 1433: 256 -> 0.81, 128 -> 0.73, 64 -> 0.60 of the roofline)
+        const bool beyond = avg_segment_nnz >= 16.0 && (double)n_src_rows * 256 * 4.0 > 768.0 * 1024 * 1024;
+        return beyond ? 128 : 256;
+    }
     int w = 64;
     while (w < d) w *= 2;
     return w;
@@ -220,7 +227,6 @@ struct LaunchShape {
     int64_t nnz_sel;
     int64_t n_out, n_src;   // output rows / rows of the gather source
     double avg;             // nonzeros per (row, hop) segment
-    bool src_vec_ok;        // gather source 16-byte addressable: base pointer, row stride, hop offsets
     int64_t ld_src;
     int d;
 };
@@ -232,14 +238,6 @@ int scratch_slice_cols(const h2gcn_plan* plan, const LaunchShape& sh) {
     if (plan->variant == 4) return 0;  // variant 4: never repack (A/B measurements)
     const int d = sh.d;
     if (sh.n_out == 0 || sh.n_src == 0 || sh.n_sel == 0) return 0;
-    if (!sh.src_vec_ok || d % 4 != 0) {
-        // odd widths / unaligned sources: zero-padded 16-byte addressable blocks, so that the float4 gather kernels
-        // serve them instead of the column-tiled kernel (up to 32 columns that kernel is the better tool: one pass of
-        // 64 lanes covers the row, and a 64-column padded copy would multiply the gathered bytes)
-        if (d <= 32) return 0;
-        const int f = plan->slice_cols;
-        return (f == 64 || f == 128 || f == 256) ? f : 64;
-    }
     if (d <= 64) return 0;
     const double src_bytes = (double)sh.n_src * d * 4.0 * (sh.adjoint ? sh.n_sel : 1);
     if (src_bytes < 512.0 * 1024 * 1024) return 0;                  // operand must be far beyond the caches
@@ -249,10 +247,12 @@ int scratch_slice_cols(const h2gcn_plan* plan, const LaunchShape& sh) {
         const int w = pick_slice_cols(d, sh.n_src, plan->slice_cols, sh.avg);
         return (w == 64 || w == 128) && d % w == 0 && w < d ? w : 0;
     }
-    if ((sh.ld_src * 4) % 128 != 0 && d > 128 && sh.avg >= 16.0 && (plan->slice_cols == 0 || plan->slice_cols == 64)) {
+    if ((sh.ld_src * 4) % 128 != 0 && d > (sh.adjoint ? 256 : 128) && sh.avg >= 16.0 && (plan->slice_cols == 0 || plan->slice_cols == 64)) {
         // rows that are not cache-line aligned and wider than one 128-column slice: line-aligned, cache-sized 64-column
-        // blocks (d = 132: +5 %, 200: +3 %, 300: +30 % including the copy; d = 100 gains nothing: two blocks fetch the
-        // same 512 B per edge as the unaligned row and pay a second index pass)
+        // blocks (forward, including the copy: d = 132: +4 %, 200: +8 %, 300: +30 %; d = 100 gains nothing: two blocks fetch
+        // the same 512 B per edge as the unaligned row and pay a second index pass).  Adjoint: its one masked slice of 256
+        // columns is already the better schedule up to d = 256 (d = 200: 0.82 plain vs 0.78 copied); beyond that the copy
+        // wins as well (d = 300: 0.72 -> 0.82)
         return 64;
     }
     return 0;
@@ -269,8 +269,8 @@ struct Schedule {
     int slice;
 };
 
-// The launch-time decisions (also reported by h2gcn_plan_schedule).  `exact_ok`: the float4 kernels can read the
-// source (16-byte addressable, valid width a multiple of 4).
+// The launch-time decisions (also reported by h2gcn_plan_schedule).  `exact_ok`: the float4 kernels can serve the
+// launch (d >= 4; narrower rows take the generic column-tiled kernel).
 Schedule decide(int variant, bool exact_ok, int d, int rows_per_wave, int n_sel, int forced_slice, int64_t n_src_rows,
                 double avg_segment_nnz) {
     Schedule sc;
@@ -290,14 +290,13 @@ Schedule decide(int variant, bool exact_ok, int d, int rows_per_wave, int n_sel,
 }
 
 template <bool SUM>
-int launch(LaunchParams& p, int variant, bool src_vec_ok, bool dst_vec_ok, bool off32, int forced_slice,
-           int64_t n_src_rows, double avg_segment_nnz, hipStream_t stream) {
+int launch(LaunchParams& p, int variant, bool off32, int forced_slice, int64_t n_src_rows, double avg_segment_nnz,
+           hipStream_t stream) {
     using namespace h2gcn;
-    const bool exact_ok = src_vec_ok && p.d_src % 4 == 0;
+    const bool exact_ok = p.d >= 4;
     const Schedule sc = decide(variant, exact_ok, p.d, p.rows_per_wave, p.n_sel, forced_slice, n_src_rows, avg_segment_nnz);
-    p.dst_scalar = (!dst_vec_ok || p.d % 4 != 0) ? 1 : 0;
-    // general store (bias / ReLU epilogue, element-wise bounded stores): dedicated instantiations
-    const bool gen = p.dst_scalar || p.bias != nullptr || p.relu != 0;
+    // general store (bias / ReLU epilogue, element-wise tail of a width that is not a multiple of 4): dedicated instantiations
+    const bool gen = p.d % 4 != 0 || p.bias != nullptr || p.relu != 0;
     // short-row kernels: shallow fallback batches (more waves per SIMD) once the gather source is far beyond the caches
     const bool short_fb4 = (double)n_src_rows * p.d * 4.0 >= 512.0 * 1024 * 1024;
     const bool pipe = sc.pipe && !gen, scalar128 = sc.scalar128, exact = sc.exact, shortrow = sc.shortrow && !gen;
@@ -353,7 +352,7 @@ int launch(LaunchParams& p, int variant, bool src_vec_ok, bool dst_vec_ok, bool 
     } else if (slice == 16) {
         H2GCN_LAUNCH(4, 4, true);  // 64-byte rows, 16 neighbours per load instruction
     } else {
-        H2GCN_LAUNCH(1, 64, false);  // no scratch and (d % 4 != 0 or unaligned source): generic column-tiled path
+        H2GCN_LAUNCH(1, 64, false);  // d < 4: generic column-tiled path
     }
 #undef H2GCN_LAUNCH
 #undef H2GCN_LAUNCH_SHORT
@@ -362,11 +361,11 @@ int launch(LaunchParams& p, int variant, bool src_vec_ok, bool dst_vec_ok, bool 
 }
 
 // Copy the gather source into the slice-major scratch and point the launch at it.
-void use_scratch(LaunchParams& p, const LaunchShape& sh, int rs, bool src_vec_ok, int64_t ld_src_hop, void* workspace,
-                 hipStream_t stream, bool* off32) {
+void use_scratch(LaunchParams& p, const LaunchShape& sh, int rs, int64_t ld_src_hop, void* workspace, hipStream_t stream,
+                 bool* off32) {
     const int n_hop = sh.adjoint ? sh.n_sel : 1;
     const int n_slices = (sh.d + rs - 1) / rs;
-    const bool vec4 = src_vec_ok && sh.d % 4 == 0;
+    const bool vec4 = sh.d % 4 == 0;
     const int64_t total = sh.n_src * (int64_t)n_slices * n_hop * (rs / (vec4 ? 4 : 1));
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 64);
     if (vec4)
@@ -377,7 +376,7 @@ void use_scratch(LaunchParams& p, const LaunchShape& sh, int rs, bool src_vec_ok
                            ld_src_hop, n_hop, sh.n_src, sh.d, n_slices, rs, (float*)workspace);
     p.src = (const float*)workspace;
     p.ld_src = rs;
-    p.d_src = (sh.d + 3) & ~3;   // lanes beyond it re-read the row's last valid float4 instead of the zero padding
+    p.d_src = (sh.d + 3) & ~3;   // zero-padded: the lane that straddles d reads its own float4; lanes beyond re-read the last one
     p.src_slice_stride = sh.n_src * (int64_t)rs * n_hop;
     for (int s = 0; s < p.n_sel; ++s) p.src_hop_off[s] = sh.adjoint ? (int64_t)s * sh.n_src * rs : 0;
     *off32 = (double)sh.n_src * (double)n_slices * rs * n_hop * 4.0 < 4294967296.0;
@@ -620,9 +619,6 @@ LaunchShape shape_of(const h2gcn_plan* plan, uint32_t mask, bool adjoint) {
     return sh;
 }
 
-bool source_vec_ok(const float* src, int64_t ld_src, int64_t ld_src_hop, int n_sel, bool adjoint) {
-    return aligned16(src) && ld_src % 4 == 0 && (!adjoint || n_sel <= 1 || ld_src_hop % 4 == 0);
-}
 }  // namespace
 
 int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, int64_t ld_src, int32_t d,
@@ -634,13 +630,10 @@ int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint
     if (d < 1 || ld_src < d) return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad width %d / stride %lld", d, (long long)ld_src);
     if (adjoint && !plan->has_transpose) return fail(H2GCN_ERR_NO_TRANSPOSE, "plan was created without H2GCN_PLAN_BUILD_TRANSPOSE");
     LaunchShape sh = shape_of(plan, mask, adjoint != 0);
-    sh.src_vec_ok = ld_src % 4 == 0;  // 16-byte aligned base pointers (and hop stride d) assumed
-    if (adjoint && sh.n_sel > 1 && d % 4 != 0) sh.src_vec_ok = false;
     sh.ld_src = ld_src;
     sh.d = d;
     const int rs = scratch_slice_cols(plan, sh);
-    const bool exact_ok = rs > 0 || (sh.src_vec_ok && d % 4 == 0);
-    const Schedule sc = decide(plan->variant, exact_ok, d, plan->rows_per_wave, sh.n_sel, rs > 0 ? rs : plan->slice_cols, sh.n_src, sh.avg);
+    const Schedule sc = decide(plan->variant, d >= 4, d, plan->rows_per_wave, sh.n_sel, rs > 0 ? rs : plan->slice_cols, sh.n_src, sh.avg);
     const int w = sc.exact ? (sc.slice > 0 ? sc.slice : 128) : d;
     if (slice_cols) *slice_cols = w;
     if (n_slices) *n_slices = sc.exact ? (d + w - 1) / w : 1;
@@ -656,7 +649,8 @@ size_t h2gcn_spmm_workspace_bytes(const h2gcn_plan_t* plan, uint32_t hop_mask, i
     uint32_t mask;
     if (resolve_mask(plan, hop_mask, &mask) != H2GCN_OK) return 0;
     LaunchShape sh = shape_of(plan, mask, adjoint != 0);
-    sh.src_vec_ok = source_vec_ok(src_dev, ld_src, ld_src_hop, sh.n_sel, adjoint != 0);
+    (void)src_dev;
+    (void)ld_src_hop;
     sh.ld_src = ld_src;
     sh.d = d;
     return scratch_bytes(sh, scratch_slice_cols(plan, sh));
@@ -702,14 +696,12 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
         memset(&p, 0, sizeof(p));
         LaunchShape sh = shape_of(plan, mask, false);
         int s = 0;
-        bool dst_vec_ok = aligned16(Y) && ldy_row % 4 == 0;
         for (int k = 0; k < plan->n_hops; ++k) {
             if (!(mask & (1u << k))) continue;
             const HopOperand& op = plan->fwd[k];
             p.hop[s] = HopCsr{op.rowptr, op.colidx, op.vals};
             p.src_hop_off[s] = 0;
             p.dst_hop_off[s] = (int64_t)s * ldy_hop;
-            dst_vec_ok = dst_vec_ok && (p.dst_hop_off[s] % 4 == 0);
             ++s;
         }
         p.n_sel = s;
@@ -733,18 +725,15 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
         // 32-bit gather offsets when the farthest byte of X is below 4 GiB
         bool off32 = ((double)(plan->n_cols > 0 ? plan->n_cols - 1 : 0) * (double)ldx + d) * 4.0 < 4294967296.0;
         int forced_slice = plan->slice_cols;
-        bool src_vec_ok = source_vec_ok(X, ldx, 0, s, false);
-        sh.src_vec_ok = src_vec_ok;
         sh.ld_src = ldx;
         sh.d = d;
         const int rs = (lo.workspace_dev && aligned16(lo.workspace_dev)) ? scratch_slice_cols(plan, sh) : 0;
         if (rs > 0 && lo.workspace_bytes >= scratch_bytes(sh, rs)) {
-            use_scratch(p, sh, rs, src_vec_ok, 0, lo.workspace_dev, (hipStream_t)stream_v, &off32);
+            use_scratch(p, sh, rs, 0, lo.workspace_dev, (hipStream_t)stream_v, &off32);
             H2GCN_HIP_TRY(hipGetLastError());
             forced_slice = rs;
-            src_vec_ok = true;
         }
-        return launch<false>(p, plan->variant, src_vec_ok, dst_vec_ok, off32, forced_slice, plan->n_cols, sh.avg, (hipStream_t)stream_v);
+        return launch<false>(p, plan->variant, off32, forced_slice, plan->n_cols, sh.avg, (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_opts_f32");
     }
@@ -804,20 +793,16 @@ int h2gcn_spmm_hops_T_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, cons
         p.n_tiles = (p.n_rows + rows_per_tile - 1) / rows_per_tile;
         p.tiles_per_xcd = (p.n_tiles + h2gcn::kNumXcd - 1) / h2gcn::kNumXcd;
         bool off32 = ((double)(plan->n_rows > 0 ? plan->n_rows - 1 : 0) * (double)ldg_row + (double)(s - 1) * (double)ldg_hop + d) * 4.0 < 4294967296.0;
-        const bool dst_vec_ok = aligned16(dX) && ldx % 4 == 0;
-        bool src_vec_ok = source_vec_ok(dY, ldg_row, ldg_hop, s, true);
         int forced_slice = plan->slice_cols;
-        sh.src_vec_ok = src_vec_ok;
         sh.ld_src = ldg_row;
         sh.d = d;
         const int rs = (lo.workspace_dev && aligned16(lo.workspace_dev) && plan->n_rows > 0) ? scratch_slice_cols(plan, sh) : 0;
         if (rs > 0 && lo.workspace_bytes >= scratch_bytes(sh, rs)) {
-            use_scratch(p, sh, rs, src_vec_ok, ldg_hop, lo.workspace_dev, (hipStream_t)stream_v, &off32);
+            use_scratch(p, sh, rs, ldg_hop, lo.workspace_dev, (hipStream_t)stream_v, &off32);
             H2GCN_HIP_TRY(hipGetLastError());
             forced_slice = rs;
-            src_vec_ok = true;
         }
-        return launch<true>(p, plan->variant, src_vec_ok, dst_vec_ok, off32, forced_slice, plan->n_rows, sh.avg, (hipStream_t)stream_v);
+        return launch<true>(p, plan->variant, off32, forced_slice, plan->n_rows, sh.avg, (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_T_f32");
     }

@@ -55,6 +55,10 @@ constexpr int kMinWavesPerSimd = H2GCN_MIN_WAVES;
 #ifndef H2GCN_SHORT_MIN_WAVES
 #define H2GCN_SHORT_MIN_WAVES 4
 #endif  // __launch_bounds__ of the fast paths (waves per SIMD the register budget must allow)
+#ifndef H2GCN_SHORT_FB4_MIN_WAVES
+#define H2GCN_SHORT_FB4_MIN_WAVES 7
+#endif  // ... of the forward short-row kernels with shallow fallback batches (memory-resident operands: occupancy buys
+        // bandwidth; fits without spilling -- the adjoint ones would spill and stay at 6)
 #ifndef H2GCN_WIDE_MIN_WAVES
 #define H2GCN_WIDE_MIN_WAVES H2GCN_MIN_WAVES
 #endif  // ... of the 128 / 256-column slices, whose lanes keep 2 / 4 partials of the canonical tree
@@ -82,8 +86,7 @@ struct LaunchParams {
     int64_t dst_hop_off[H2GCN_MAX_HOPS]; // element offset added to the output for hop s (ignored in SUM mode)
     int n_sel;
     int d;           // feature columns of the output
-    int d_src;       // valid columns of the gather source (== d, or the zero-padded width of a scratch copy)
-    int dst_scalar;  // general-store kernels: store element-wise with a column bound (d % 4 != 0 / unaligned output)
+    int d_src;       // readable columns of a gather-source row (== d in place; d rounded up to 4 in the zero-padded scratch)
     int64_t n_rows;  // rows of the output
     const float* src;
     int64_t ld_src;
@@ -110,13 +113,15 @@ template <>
 struct VecT<1> {
     using type = float;
 };
+// aligned(4): global_load/store_dwordx2/x4 on gfx9 only need dword alignment (measured: tools/unaligned_vec_probe), so
+// feature rows of ANY width and any 4-byte aligned base are gathered and stored with 16-byte instructions
 template <>
 struct VecT<2> {
-    using type = float __attribute__((ext_vector_type(2)));
+    typedef float type __attribute__((ext_vector_type(2), aligned(4)));
 };
 template <>
 struct VecT<4> {
-    using type = float __attribute__((ext_vector_type(4)));
+    typedef float type __attribute__((ext_vector_type(4), aligned(4)));
 };
 
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -431,32 +436,32 @@ __device__ __forceinline__ void store_vec(float* p, const float (&acc)[VEC]) {
     }
 }
 
-// Store of one lane's VEC finished sums, columns col .. col+VEC-1 of an output row (`ptr` points at column col).
-// Plain kernels: one 16-byte store when the whole vector lies inside d (`whole`).  General-store kernels (GEN) add the
-// bias / ReLU epilogue and, for outputs that are not 16-byte addressable or d % 4 != 0 (p.dst_scalar), element-wise
-// stores bounded by d -- which is how odd feature widths (reference: any b.shape[1], _layers.py:62-76) run on the
-// float4 gather kernels.
+// Store of one lane's VEC finished sums.  The lane's nominal columns are col0 .. col0+VEC-1; its sums are those of
+// columns ecol .. ecol+VEC-1 (ecol == col0 except in the TAIL lane of a width that is not a multiple of VEC, which
+// gathered the row's last VEC columns, overlapping its left neighbour -- see the kernel).  `row` points at column 0 of
+// the output row.  Plain kernels: one 16-byte store when the whole vector lies inside d.  General-store kernels (GEN)
+// add the bias / ReLU epilogue and let the tail lane store the columns it owns element-wise -- which is how odd feature
+// widths (reference: any b.shape[1], _layers.py:62-76) run on the float4 gather kernels.
 template <int VEC, bool GEN, typename P>
-__device__ __forceinline__ void store_out(const P& p, float* ptr, int col, float (&tot)[VEC], bool whole) {
+__device__ __forceinline__ void store_out(const P& p, float* row, int col0, int ecol, float (&tot)[VEC]) {
+    if (col0 + VEC <= p.d) {
+        if constexpr (GEN) epilogue<VEC>(tot, p.bias, p.relu, col0);
+        store_vec<VEC>(row + col0, tot);
+        return;
+    }
     if constexpr (GEN) {
-        if (p.dst_scalar) {
+        if (col0 < p.d) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                if (col + i < p.d) {
+                const int c = ecol + i;
+                if (c >= col0 && c < p.d) {
                     float t = tot[i];
-                    if (p.bias) t += p.bias[col + i];
+                    if (p.bias) t += p.bias[c];
                     if (p.relu) t = fmaxf(t, 0.f);
-                    __builtin_nontemporal_store(t, ptr + i);
+                    __builtin_nontemporal_store(t, row + c);
                 }
             }
-            return;
         }
-        if (whole) {
-            epilogue<VEC>(tot, p.bias, p.relu, col);
-            store_vec<VEC>(ptr, tot);
-        }
-    } else {
-        if (whole) store_vec<VEC>(ptr, tot);
     }
 }
 
@@ -479,7 +484,7 @@ __device__ __forceinline__ void store_out(const P& p, float* ptr, int col, float
 //        (memory-resident operands: occupancy buys bandwidth), 8 at 5 (cache-resident operands: the longer segments'
 //        loads in flight matter more)
 template <int VEC, int LPR, bool EXACT, bool SUM, bool OFF32, bool PIPE = false, bool SHORT = false, bool EPI = false, int FB = 8>
-__global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : (LPR >= 32 ? H2GCN_WIDE_MIN_WAVES : kMinWavesPerSimd)) : 2) void spmm_hops_kernel(const LaunchParams p) {
+__global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? (FB == 4 && !SUM ? H2GCN_SHORT_FB4_MIN_WAVES : H2GCN_SHORT_MIN_WAVES) : (LPR >= 32 ? H2GCN_WIDE_MIN_WAVES : kMinWavesPerSimd)) : 2) void spmm_hops_kernel(const LaunchParams p) {
     static_assert(EXACT || LPR == kWave, "column-tiled path uses the whole wave per row");
     __shared__ float partial[kWavesPerBlock][kMaxTileCols];
     using off_t = typename std::conditional<OFF32, uint32_t, int64_t>::type;
@@ -498,11 +503,16 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : (L
     const int col_begin = EXACT ? slice * (VEC * LPR) : 0;
     const int col_end = EXACT ? col_begin + VEC * LPR : p.d;
     const int64_t src_col_begin = EXACT ? (int64_t)slice * p.src_slice_stride : 0;  // where this slice starts in the source
-    // EXACT: lanes of the (possibly partial) last slice that lie beyond the source's valid columns gather the last
-    // valid float4 instead; `whole` = this lane's float4 lies inside d (it may store with one 16-byte store)
-    const int valid_lanes = EXACT ? min(LPR, (p.d_src - col_begin) / VEC) : LPR;
-    const int li_src = EXACT ? min(li, valid_lanes - 1) : li;
-    const bool whole = !EXACT || (col_begin + li * VEC + VEC <= p.d);
+    // EXACT: this lane's nominal columns are lcol .. lcol+VEC-1.  A lane whose vector would stick out beyond the readable
+    // width of the source row gathers the row's LAST VEC columns instead (ecol = d_src - VEC: same cache line, no extra
+    // traffic, no predication in the gather loop).  For the lane that straddles the end (width not a multiple of VEC) those
+    // columns overlap its left neighbour's and include the ones it owns; lanes entirely beyond the end own nothing.
+    const int lcol = col_begin + li * VEC;
+    const int ecol = EXACT ? ((lcol + VEC <= p.d_src) ? lcol : p.d_src - VEC) : lcol;
+    // byte offset of ecol inside the slice, biased by VEC elements so that it is never negative (the tail of a slice that
+    // holds fewer than VEC columns reaches back into the previous slice); the wave-uniform base is lowered accordingly
+    const off_t lane_off0 = (off_t)((ecol - col_begin + VEC) * 4);
+    constexpr int kBias = EXACT ? VEC : 0;
 
     if (b < p.n_long) {
         // ---- long segment: the 4 waves of this workgroup share one (row, hop) [forward] / one row [SUM] ----
@@ -517,16 +527,22 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : (L
             for (int s = s_first; s < s_last; ++s) {
                 const HopCsr& h = p.hop[s];
                 const int64_t sb = h.rowptr[row], se = h.rowptr[row + 1];
-                const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin + (col0 - col_begin)),
-                                             (off_t)(li_src * VEC * 4), (off_t)(p.ld_src * 4)};
+                const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin + (col0 - col_begin) - kBias),
+                                             EXACT ? lane_off0 : (off_t)(li * VEC * 4), (off_t)(p.ld_src * 4)};
                 accumulate_segment<VEC, LPR, !EXACT, OFF32>(h.colidx, h.vals, sb, se, wave, kWavesPerBlock, addr, lane,
                                                             lane_active, acc);
             }
             float tot[VEC];
             fold_tree<VEC, LPR, NP>(acc, tot);
             if (g == 0) {
+                // this lane's sums belong to columns ecol .. ecol+VEC-1 (tile-relative index below); a tail lane overlaps its
+                // left neighbour with identical values, lanes entirely beyond the row's end contribute nothing
+                const int rel = EXACT ? ecol - col_begin : li * VEC;
+                if (!EXACT || lcol < p.d_src) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) partial[wave][li * VEC + i] = tot[i];
+                    for (int i = 0; i < VEC; ++i)
+                        if (rel + i >= 0) partial[wave][rel + i] = tot[i];
+                }
             }
             __syncthreads();
             // fixed-order sum of the 4 wave totals; thread c owns column col0 + c
@@ -572,7 +588,7 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : (L
         constexpr int G = kWave / LPR;
         const int short_max = min(LPR, p.long_threshold - 1);
         const int n_blocks = (rows_here + G - 1) / G;       // row blocks of G consecutive rows
-        const GatherAddr<OFF32> addr0{nullptr, (off_t)(li_src * VEC * 4), (off_t)(p.ld_src * 4)};
+        const GatherAddr<OFF32> addr0{nullptr, lane_off0, (off_t)(p.ld_src * 4)};
         // wave-per-segment walk of one row (all hops in SUM mode, hop `s_only` otherwise) -- the general path
         auto row_wave_wide = [&](int r, int s_first, int s_last) {
             float acc[NP][VEC];
@@ -589,22 +605,19 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : (L
                 if (!SUM && se - sb >= p.long_threshold) continue;
                 const HopCsr& h = p.hop[s];
                 GatherAddr<OFF32> addr = addr0;
-                addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin);
+                addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin - kBias);
                 accumulate_segment<VEC, LPR, false, OFF32, FB>(h.colidx, h.vals, sb, se, 0, 1, addr, lane, true, acc);
                 if constexpr (!SUM) {
                     float tot[VEC];
                     fold_tree<VEC, LPR, NP>(acc, tot);
-                    if (g == 0)
-                        store_out<VEC, EPI>(p, p.dst + (row0 + r) * p.ld_dst + p.dst_hop_off[s] + col_begin + li * VEC,
-                                            col_begin + li * VEC, tot, whole);
+                    if (g == 0) store_out<VEC, EPI>(p, p.dst + (row0 + r) * p.ld_dst + p.dst_hop_off[s], lcol, ecol, tot);
                     zero_acc<VEC, NP>(acc);
                 }
             }
             if constexpr (SUM) {
                 float tot[VEC];
                 fold_tree<VEC, LPR, NP>(acc, tot);
-                if (g == 0)
-                    store_out<VEC, EPI>(p, p.dst + (row0 + r) * p.ld_dst + col_begin + li * VEC, col_begin + li * VEC, tot, whole);
+                if (g == 0) store_out<VEC, EPI>(p, p.dst + (row0 + r) * p.ld_dst, lcol, ecol, tot);
             }
         };
         // (begin, length) of the segment (hop s, row b*G + g) for this lane's group; length -1 for rows beyond the tile
@@ -651,13 +664,11 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : (L
                     float part[kTreeParts][VEC];
                     zero_acc<VEC, kTreeParts>(part);
                     GatherAddr<OFF32> addr = addr0;
-                    addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin);
+                    addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin - kBias);
                     accumulate_grouped<VEC, LPR, OFF32>(c, v, len, n_max, lane, addr, part);
                     float tot[VEC];
                     combine_partials<VEC>(part, tot);
-                    if (len >= 0)
-                        store_out<VEC, EPI>(p, p.dst + (row0 + blk * G + g) * p.ld_dst + p.dst_hop_off[s] + col_begin + li * VEC,
-                                            col_begin + li * VEC, tot, whole);
+                    if (len >= 0) store_out<VEC, EPI>(p, p.dst + (row0 + blk * G + g) * p.ld_dst + p.dst_hop_off[s], lcol, ecol, tot);
                 } else {
                     for (int gg = 0; gg < G && blk * G + gg < rows_here; ++gg) row_wave_wide(blk * G + gg, s, s + 1);
                 }
@@ -706,13 +717,12 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : (L
 #pragma unroll
                         for (int gg = 0; gg < G; ++gg) n_max = max(n_max, __builtin_amdgcn_readlane(len, gg * LPR));
                         GatherAddr<OFF32> addr = addr0;
-                        addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin);
+                        addr.base = reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin - kBias);
                         accumulate_grouped<VEC, LPR, OFF32>(c, v, len, n_max, lane, addr, part);
                     }
                     float tot[VEC];
                     combine_partials<VEC>(part, tot);
-                    if (valid)
-                        store_out<VEC, EPI>(p, p.dst + (row0 + blk * G + g) * p.ld_dst + col_begin + li * VEC, col_begin + li * VEC, tot, whole);
+                    if (valid) store_out<VEC, EPI>(p, p.dst + (row0 + blk * G + g) * p.ld_dst, lcol, ecol, tot);
                 } else {
                     if (blk + 1 < n_blocks) fetch(blk + 1, 0, nxt_short);
                     for (int gg = 0; gg < G && blk * G + gg < rows_here; ++gg) row_wave_wide(blk * G + gg, 0, n_sel);
@@ -757,17 +767,15 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : (L
             const int r = q / n_sel;
             const int64_t row = row0 + r;
             const HopCsr& h = p.hop[s_cur];
-            const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s_cur] + src_col_begin),
-                                         (off_t)(li_src * VEC * 4), (off_t)(p.ld_src * 4)};
+            const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s_cur] + src_col_begin - kBias),
+                                         lane_off0, (off_t)(p.ld_src * 4)};
             accumulate_segment_prefetched<VEC, LPR, OFF32>(h.colidx, h.vals, b_cur, e_cur, c_cur, v_cur, addr, lane, acc);
             const bool skipped = (skip >> q) & 1u;
             if (!SUM || s_cur == n_sel - 1) {
                 if (!skipped) {
                     float tot[VEC];
                     fold_tree<VEC, LPR, NP>(acc, tot);
-                    if (g == 0)
-                        store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_cur]) + col_begin + li * VEC,
-                                            col_begin + li * VEC, tot, whole);
+                    if (g == 0) store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_cur]), lcol, ecol, tot);
                 }
                 zero_acc<VEC, NP>(acc);
             }
@@ -794,14 +802,14 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : (L
                 const int64_t sb = seg_bound(l0), se = seg_bound(l0 + 1);
                 if (!SUM && se - sb >= p.long_threshold) continue;  // a workgroup of the long path owns it
                 const HopCsr& h = p.hop[s];
-                const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin + (col0 - col_begin)),
-                                             (off_t)(li_src * VEC * 4), (off_t)(p.ld_src * 4)};
+                const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin + (col0 - col_begin) - kBias),
+                                             EXACT ? lane_off0 : (off_t)(li * VEC * 4), (off_t)(p.ld_src * 4)};
                 accumulate_segment<VEC, LPR, !EXACT, OFF32>(h.colidx, h.vals, sb, se, 0, 1, addr, lane, lane_active, acc);
                 if constexpr (!SUM) {
                     float tot[VEC];
                     fold_tree<VEC, LPR, NP>(acc, tot);
                     if (g == 0 && lane_active)
-                        store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + p.dst_hop_off[s] + col0 + li * VEC, col0 + li * VEC, tot, whole);
+                        store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + p.dst_hop_off[s], EXACT ? lcol : col0 + li * VEC, EXACT ? ecol : col0 + li * VEC, tot);
                     zero_acc<VEC, NP>(acc);
                 }
             }
@@ -809,7 +817,7 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? H2GCN_SHORT_MIN_WAVES : (L
                 float tot[VEC];
                 fold_tree<VEC, LPR, NP>(acc, tot);
                 if (g == 0 && lane_active)
-                    store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + col0 + li * VEC, col0 + li * VEC, tot, whole);
+                    store_out<VEC, EPI>(p, p.dst + row * p.ld_dst, EXACT ? lcol : col0 + li * VEC, EXACT ? ecol : col0 + li * VEC, tot);
             }
         }
     }

@@ -137,7 +137,7 @@ int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t*
  * columns per slice of the slice-major schedule, number of slices, segment walk (0 = wave per segment, 1 = the same
  * with index prefetch across segments, 2 = short-row mode: one lane group per segment), whether a launch that is given
  * scratch would gather from a slice-major copy.  adjoint != 0 asks about h2gcn_spmm_hops_T_f32 (ld_src = ldg_row,
- * hop stride d).  16-byte aligned base pointers are assumed.  Any out pointer may be NULL. */
+ * hop stride d).  Any out pointer may be NULL. */
 int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, int64_t ld_src, int32_t d,
                         int32_t* slice_cols, int32_t* n_slices, int32_t* segment_walk, int32_t* scratch_copy);
 
@@ -157,10 +157,12 @@ int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint
  *
  *   X_dev   fp32, n_cols rows of d values, row stride ldx >= d (elements)
  *   Y_dev   fp32, must not alias X
- *   d       feature width >= 1, any value (the reference accepts any b.shape[1], _layers.py:62-76).  16-byte
- *           addressable X with d % 4 == 0 is gathered in place by the float4 kernels (column slices of 16..256); any
- *           other width / alignment runs on the same kernels through the zero-padded scratch copy when the launch is
- *           given scratch (h2gcn_spmm_hops_opts_f32), else on the generic column-tiled kernel.
+ *   d       feature width >= 1, any value, any 4-byte aligned X / Y and any strides (the reference accepts any
+ *           b.shape[1], _layers.py:62-76; raw feature widths such as Cora's 1433 occur).  Every d >= 4 runs on the
+ *           float4 gather kernels, in place: 16-byte global loads and stores need only dword alignment on gfx950, and
+ *           in a row whose width is not a multiple of 4 the lane that straddles the end gathers the row's last four
+ *           columns (overlapping its neighbour) and stores the ones it owns.  d < 4 takes a generic column-tiled
+ *           kernel.  Fastest when rows are cache-line aligned (ldx a multiple of 32 floats).
  *
  * Floating point: fp32 multiply-add per nonzero in ONE canonical summation tree per output element -- neighbour j of
  * the row (ascending column order, the reference's order after tf.sparse.reorder, _dataset.py:535) is added into
@@ -178,21 +180,19 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
  * workspace / workspace_bytes: caller-provided scratch for a slice-major copy of the gather source (one streaming pass,
  *   a few % of the launch), from which the launch then gathers.  h2gcn_spmm_workspace_bytes() says how much scratch a
  *   launch wants (0 = the plain launch is already the fastest); NULL / too small simply selects the plain launch.
- *   The copy is used (a) when the row stride of X is a multiple of 1 KiB (e.g. a contiguous [N, 256] embedding) and
- *   the operand is far beyond the caches: gathering column slices straight out of such rows wastes three quarters of
- *   the cache sets; (b) when the rows are wide and not cache-line aligned (ld*4 not a multiple of 128, d > 128): the
- *   copy's 64-column blocks are; (c) when d % 4 != 0 or the source is not 16-byte addressable (raw feature widths:
- *   Cora 1433, citeseer 3703): the copy is zero-padded to whole blocks, so the float4 gather kernels serve the launch
- *   instead of the generic column-tiled kernel.  Results are bit-identical with and without scratch (canonical
- *   summation tree).  The scratch is only used by this launch (on `stream`); launches that may run concurrently need
- *   separate scratch.
+ *   The copy is a pure performance device, used (a) when the row stride of X is a multiple of 1 KiB (e.g. a contiguous
+ *   [N, 256] embedding) and the operand is far beyond the caches: gathering column slices straight out of such rows
+ *   wastes three quarters of the cache sets; (b) when the rows are wide and not cache-line aligned (ld*4 not a multiple
+ *   of 128; forward d > 128, adjoint d > 256) on such an operand: the copy's 64-column blocks are aligned (zero-padded
+ *   when d is not a multiple of 4).  Results are bit-identical with and without scratch (canonical summation tree).
+ *   The scratch is only used by this launch (on `stream`); launches that may run concurrently need separate scratch.
  * bias / H2GCN_LAUNCH_RELU: fused epilogue of the store, Y = act(A X + bias[c]) -- what SparseDense.call applies
  *   after its sparse product (reference h2gcn/models/_layers.py:45-52: `+ self.bias`, then `self.activation`), so
  *   that the feature embedding needs no second pass over its output.  bias: d floats (device) or NULL.  Forward only.
  *
  * h2gcn_spmm_workspace_bytes: adjoint != 0 asks about h2gcn_spmm_hops_T_opts_f32; src_dev / ld_src / ld_src_hop
- *   describe the gather source of that launch (forward: X_dev, ldx, 0; adjoint: dY_dev, ldg_row, ldg_hop) -- the
- *   pointer is only inspected for its alignment, never dereferenced.
+ *   describe the gather source of that launch (forward: X_dev, ldx, 0; adjoint: dY_dev, ldg_row, ldg_hop); the pointer
+ *   and the hop stride are reserved (alignment no longer matters) and never dereferenced.
  */
 #define H2GCN_LAUNCH_RELU 0x1u
 typedef struct h2gcn_launch_opts {
@@ -222,8 +222,8 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
 int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* dY_dev, int64_t ldg_row,
                           int64_t ldg_hop, int32_t d, float* dX_dev, int64_t ldx, void* stream);
 /* The adjoint with options: only workspace_dev / workspace_bytes are used (bias_dev and flags must be 0).  With
- * scratch the stacked gradient is copied slice-major per hop when its rows are wide and not cache-line aligned, or
- * when d % 4 != 0 / dY is not 16-byte addressable -- same rules, same bits as the forward launch. */
+ * scratch the stacked gradient is copied slice-major per hop when its rows are wide (d > 256) and not cache-line
+ * aligned on an operand far beyond the caches -- same bits as the plain launch. */
 int h2gcn_spmm_hops_T_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* dY_dev, int64_t ldg_row,
                                int64_t ldg_hop, int32_t d, float* dX_dev, int64_t ldx,
                                const h2gcn_launch_opts* opts, void* stream);

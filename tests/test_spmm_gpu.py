@@ -461,13 +461,15 @@ def test_bits_are_the_canonical_tree_for_every_schedule(d, thr):
     xt, wt = torch.from_numpy(x).to(dev()), torch.from_numpy(w).to(dev())
     for variant in (0, 2, 3, 5):
         for sc in (0, 64, 128, 256):
+            if sc == 0 and 4 <= d < 64:
+                continue   # below 64 columns the heuristic picks the narrow slices (own tree; never cut by a partition)
             plan = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr, variant=variant, slice_cols=sc)
             for use_ws in (True, False):
                 plan.use_workspace = use_ws
                 assert np.array_equal(plan.spmm(xt).cpu().numpy(), tree), (variant, sc, use_ws, plan.schedule(d))
                 assert np.array_equal(plan.spmm_t(wt).cpu().numpy(), tree_t), (variant, sc, use_ws, "adjoint")
             assert np.array_equal(plan.spmm(xt, hops=[1]).cpu().numpy(), tree[:, 1:]), (variant, sc)
-    plan = HopPlan.from_scipy(hops, dev(), long_row_threshold=thr)
+    plan = HopPlan.from_scipy(hops, dev(), long_row_threshold=thr, slice_cols=0 if d >= 64 or d < 4 else 64)
     if d >= 128:   # feature chunks of unequal widths (what the multi-GPU pipeline does), written into one output
         for widths in ([64, d - 64], [d - 64, 64], [d // 2, d - d // 2]):
             y = torch.empty((n, 2, d), device=dev())
@@ -477,7 +479,7 @@ def test_bits_are_the_canonical_tree_for_every_schedule(d, thr):
                 c0 += wd
             assert np.array_equal(y.cpu().numpy(), tree), widths
     # a row block (what a rank of the row partition computes) gives the same rows
-    sub = HopPlan.from_scipy([h[400:900] for h in hops], dev(), long_row_threshold=thr)
+    sub = HopPlan.from_scipy([h[400:900] for h in hops], dev(), long_row_threshold=thr, slice_cols=0 if d >= 64 or d < 4 else 64)
     assert np.array_equal(sub.spmm(xt).cpu().numpy(), tree[400:900])
 
 
@@ -589,17 +591,16 @@ def test_hop_selection_and_strided_output():
 
 def test_unaligned_operands_and_odd_widths():
     """Views whose base is not 16-byte aligned, odd row strides, d % 4 != 0 (raw feature widths: the reference takes any
-    b.shape[1], _layers.py:62-76): with scratch the launch gathers from the zero-padded slice-major copy on the float4
-    kernels, without it the generic column-tiled kernel runs -- same bits (canonical tree), guard columns untouched."""
-    import ctypes as C
-
-    from h2gcn_amd import HopPlan, _capi
+    b.shape[1], _layers.py:62-76): gathered IN PLACE by the float4 kernels (16-byte global loads / stores only need dword
+    alignment on gfx950; the lane that straddles the end of a row overlaps its neighbour) -- same bits as every other
+    schedule (canonical tree), guard columns untouched, with and without scratch, forward, adjoint and fused epilogue."""
+    from h2gcn_amd import HopPlan
 
     hops = [rand_csr(400, 400, 0.05, 1), rand_csr(400, 400, 0.1, 2)]
     hops[0] = sp.csr_matrix(sp.vstack([hops[0][:3], sp.csr_matrix(np.full((1, 400), 0.01, dtype=np.float32)), hops[0][4:]]))
-    plan = HopPlan.from_scipy(hops, dev(), build_transpose=True)
-    L = _capi.lib()
-    for d in (128, 133, 1433 // 7, 3):
+    for d in (128, 133, 1433 // 7, 65, 67, 3):
+        plan = HopPlan.from_scipy(hops, dev(), build_transpose=True)
+        assert plan.schedule(d, ld_src=d + 3)["slice_cols"] in ((64, 128, 256) if d >= 4 else (d,))
         x = np.random.default_rng(d).uniform(-1, 1, (400, d)).astype(np.float32)
         w = np.random.default_rng(d + 1).uniform(-1, 1, (400, 2, d)).astype(np.float32)
         tree = og.gcn_layer_tree(hops, x)
@@ -608,7 +609,6 @@ def test_unaligned_operands_and_odd_widths():
         xbuf = torch.zeros((400, d + 3), device=dev())
         xbuf[:, 1:1 + d] = torch.from_numpy(x).to(dev())
         xv = xbuf[:, 1:1 + d]
-        assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 0, C.c_void_p(xv.data_ptr()), d + 3, 0, d) == (400 * -(-d // 64) * 64 * 4 if d > 32 else 0)
         wbuf = torch.zeros((400, 2 * d + 5), device=dev())
         wv = wbuf[:, 2:2 + 2 * d].view(400, 2, d)
         wv.copy_(torch.from_numpy(w))
@@ -619,10 +619,37 @@ def test_unaligned_operands_and_odd_widths():
             assert np.array_equal(y.cpu().numpy(), tree), (d, use_ws)
             assert bool((ybuf[:, :2] == 5.0).all()) and bool((ybuf[:, 2 + 2 * d:] == 5.0).all())
             assert np.array_equal(plan.spmm_t(wv).cpu().numpy(), tree_t), (d, use_ws)
-            # fused epilogue on the same path
             b = torch.from_numpy(np.random.default_rng(5).uniform(-0.5, 0.5, d).astype(np.float32)).to(dev())
             yb = plan.spmm(xv, bias=b, relu=True)
             assert torch.equal(yb, torch.relu(torch.from_numpy(tree).to(dev()) + b)), (d, use_ws)
+        # the LAST row of X ends exactly at the end of its allocation: the tail lane must not read past it
+        xt = torch.from_numpy(x).to(dev())
+        assert np.array_equal(plan.spmm(xt).cpu().numpy(), tree)
+
+
+def test_odd_width_scratch_copy_of_wide_unaligned_rows():
+    """d = 203 on an operand far beyond the caches: rows of 812 B are wide and not cache-line aligned, so a launch with
+    scratch gathers from the zero-padded slice-major copy (element-wise repack) -- bit-identical to the in-place launch."""
+    import ctypes as C
+
+    from h2gcn_amd import HopPlan, _capi, synth
+
+    n, d, device = 700_000, 203, dev()
+    degs = [synth.synth_degrees(n, 12_500_000, s, n) for s in (15, 16)]
+    csr = [synth.synth_hop_rows(degs[k], n, (15, 16)[k], 0, n, device) for k in range(2)]
+    plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n, build_transpose=True)
+    x = synth.synth_features(d, 17, 0, n, device)
+    assert _capi.lib().h2gcn_spmm_workspace_bytes(plan._handle, 0, 0, C.c_void_p(x.data_ptr()), d, 0, d) == n * 4 * 64 * 4
+    assert plan.schedule(d)["scratch_copy"] and not plan.schedule(d, adjoint=True)["scratch_copy"]
+    y_ws = plan.spmm(x)
+    plan.use_workspace = False
+    assert torch.equal(y_ws, plan.spmm(x))
+    g = synth.synth_features(2 * 303, 9, 0, n, device).view(n, 2, 303)      # adjoint: copied beyond 256 columns
+    plan.use_workspace = True
+    assert plan.schedule(303, adjoint=True)["scratch_copy"]
+    dx_ws = plan.spmm_t(g)
+    plan.use_workspace = False
+    assert torch.equal(dx_ws, plan.spmm_t(g))
 
 
 def test_c_abi_from_plain_c():
