@@ -334,6 +334,10 @@ def main():
                     why = f"warm-up: {type(e).__name__}: {e}"
                 if not all_ok(why is None):
                     rejected[key] = why or "warm-up failed on another rank"
+                    try:
+                        cand.close()       # collective: every rank is here
+                    except Exception:  # noqa: BLE001
+                        pass
                     continue
                 cands[key] = (timed_ms(lambda: cand(x_local, out=y), 3), cand, ex, spec)
         if not cands:

@@ -50,7 +50,10 @@ EXPORTED_SYMBOLS = (
     "h2gcn_ring_scratch_bytes",
     "h2gcn_ring_count",
     "h2gcn_ring_fill",
+    "h2gcn_ring_count_rows",
+    "h2gcn_ring_fill_rows",
     "h2gcn_hop_normalize",
+    "h2gcn_hop_normalize_rows",
     "h2gcn_xchg_create",
     "h2gcn_xchg_export",
     "h2gcn_xchg_connect",
@@ -172,6 +175,13 @@ def lib() -> C.CDLL:
     L.h2gcn_ring_count.argtypes = ring_common + [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_size_t, C.c_void_p]
     L.h2gcn_ring_fill.restype = C.c_int
     L.h2gcn_ring_fill.argtypes = ring_common + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    ring_rows = [C.c_int64, C.c_int64, C.c_int64] + ring_common[1:]      # (n, row_begin, n_rows, a_rowptr, ...)
+    L.h2gcn_ring_count_rows.restype = C.c_int
+    L.h2gcn_ring_count_rows.argtypes = ring_rows + [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_size_t, C.c_void_p]
+    L.h2gcn_ring_fill_rows.restype = C.c_int
+    L.h2gcn_ring_fill_rows.argtypes = ring_rows + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.h2gcn_hop_normalize_rows.restype = C.c_int
+    L.h2gcn_hop_normalize_rows.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.h2gcn_hop_normalize.restype = C.c_int
     L.h2gcn_hop_normalize.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.h2gcn_xchg_create.restype = C.c_int

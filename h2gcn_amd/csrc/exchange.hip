@@ -111,6 +111,15 @@ __global__ void wait_kernel(const uint32_t* flag, uint32_t seq, long long timeou
     if (threadIdx.x == 0) wait_flag(flag, seq, timeout_ticks, err);
 }
 
+// A wait that gave up must not leave plausible numbers behind: once the error word is set, every block that was (or
+// would have been) filled from a peer is overwritten with NaN, so that whatever consumes it fails loudly (a NaN loss)
+// even if nobody asks h2gcn_xchg_status.  Launched after each copy-engine pull; does nothing while *err == 0.
+__global__ void poison_kernel(const int* err, float* dst, size_t n_floats) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) return;
+    const float nan = __int_as_float(0x7fc00000);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_floats; i += (size_t)gridDim.x * blockDim.x) dst[i] = nan;
+}
+
 // out[i] = sum over ranks q = 0 .. world-1 (ascending: a fixed order, the result does not depend on arrival order) of
 // block q, where block `rank` is this rank's own contribution and the others arrived in recv[q]
 __global__ void sum_blocks_kernel(const float* __restrict__ recv, const float* __restrict__ own, int world, int rank,
@@ -132,7 +141,12 @@ __global__ __launch_bounds__(kPullThreads) void pull_kernel(PeerTable peers, con
     __shared__ int ok;
     if (threadIdx.x == 0) ok = wait_flag(my_flags + channel * kMaxWorld + q, seq, timeout_ticks, err) ? 1 : 0;
     __syncthreads();
-    if (!ok) return;
+    if (!ok) {  // timed out: poison this peer's block (see poison_kernel)
+        float* bad = reinterpret_cast<float*>(full + (size_t)q * bytes);
+        const float nan = __int_as_float(0x7fc00000);
+        for (size_t j = (size_t)sub * kPullThreads + threadIdx.x; j < bytes / 4; j += (size_t)kPullBlocksPerPeer * kPullThreads) bad[j] = nan;
+        return;
+    }
     // the acquire above ran on one wave; make sure no stale line of the peer's slot (read two steps ago) is
     // served from this XCD's caches to the other waves
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -179,6 +193,8 @@ struct h2gcn_xchg {
     std::vector<hipEvent_t> fence;      // [n_channels]
     std::vector<hipEvent_t> pulled;     // [n_channels * world]
     std::vector<char> pulled_valid;     // event has been recorded at least once
+    std::vector<hipEvent_t> summed;     // [n_channels]: end of the reduce-scatter's fixed-order sum (it reads this rank's own
+    std::vector<char> summed_valid;     // slot, so the next begin on the channel -- on whatever stream -- must wait for it)
     std::vector<uint32_t> seq;          // [n_channels]
     std::vector<char> open_channel;     // begin without end (1 = all-gather, 2 = reduce-scatter)
     // reduce-scatter state per channel: receive buffer (world blocks) and what `end` has to sum
@@ -198,6 +214,8 @@ void release(h2gcn_xchg* x) {
     for (hipEvent_t e : x->fence)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : x->pulled)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : x->summed)
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : x->streams)
         if (s) (void)hipStreamDestroy(s);
@@ -230,6 +248,8 @@ int issue_pulls(h2gcn_xchg* x, int channel, uint32_t seq, size_t src_off, size_t
                                x->timeout_ticks, x->err);
             H2GCN_HIP_TRY(hipGetLastError());
             H2GCN_HIP_TRY(hipMemcpyAsync(dst + (size_t)q * bytes, x->peers.data[q] + src_off, bytes, hipMemcpyDeviceToDevice, ps));
+            hipLaunchKernelGGL(poison_kernel, dim3(64), dim3(256), 0, ps, (const int*)x->err, (float*)(dst + (size_t)q * bytes), bytes / 4);
+            H2GCN_HIP_TRY(hipGetLastError());
             const size_t ei = (size_t)channel * x->world + q;
             H2GCN_HIP_TRY(hipEventRecord(x->pulled[ei], ps));
             x->pulled_valid[ei] = 1;
@@ -305,6 +325,9 @@ int h2gcn_xchg_create(int world, int rank, int n_channels, size_t slot_bytes, in
         x->pulled.assign((size_t)n_channels * world, nullptr);
         for (auto& e : x->pulled) H2GCN_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         x->pulled_valid.assign((size_t)n_channels * world, 0);
+        x->summed.assign(n_channels, nullptr);
+        for (auto& e : x->summed) H2GCN_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        x->summed_valid.assign(n_channels, 0);
         x->seq.assign(n_channels, 0);
         x->open_channel.assign(n_channels, 0);
         x->rs_recv.assign(n_channels, nullptr);
@@ -402,6 +425,7 @@ static int allgather_impl(h2gcn_xchg_t* x, int channel, const float* src, int64_
         for (int q = 0; q < x->world; ++q)
             if (x->pulled_valid[(size_t)channel * x->world + q])
                 H2GCN_HIP_TRY(hipStreamWaitEvent(stream, x->pulled[(size_t)channel * x->world + q], 0));
+        if (x->summed_valid[channel]) H2GCN_HIP_TRY(hipStreamWaitEvent(stream, x->summed[channel], 0));
         if (rows_per_rank > 0) {
             const bool vec4 = width % 4 == 0 && ld_src % 4 == 0 && ((uintptr_t)src & 15u) == 0 && ((uintptr_t)own & 15u) == 0;
             const int64_t total = rows_per_rank * (vec4 ? width / 4 : width);
@@ -443,7 +467,7 @@ int h2gcn_xchg_allgather_pull(h2gcn_xchg_t* x, int channel, int64_t rows_per_ran
     if (x->open_channel[channel] != 3) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d: allgather_pull without allgather_post", channel);
     x->open_channel[channel] = 0;  // allgather_impl re-checks "not open"
     const int st = allgather_impl(x, channel, nullptr, width, 0, rows_per_rank, width, full, nullptr, false, true);
-    x->open_channel[channel] = 1;
+    x->open_channel[channel] = st == H2GCN_OK ? 1 : 3;  // a failed pull leaves the channel "posted": it can be retried
     return st;
 }
 
@@ -491,6 +515,7 @@ int h2gcn_xchg_reduce_scatter_begin(h2gcn_xchg_t* x, int channel, const float* s
         for (int q = 0; q < x->world; ++q)
             if (x->pulled_valid[(size_t)channel * x->world + q])
                 H2GCN_HIP_TRY(hipStreamWaitEvent(stream, x->pulled[(size_t)channel * x->world + q], 0));
+        if (x->summed_valid[channel]) H2GCN_HIP_TRY(hipStreamWaitEvent(stream, x->summed[channel], 0));
         if (bytes > 0) H2GCN_HIP_TRY(hipMemcpyAsync(x->data + slot_off, src, bytes, hipMemcpyDeviceToDevice, stream));
         if (x->world > 1) {
             hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, stream, x->peers, x->world, x->rank, channel, seq);
@@ -520,13 +545,10 @@ int h2gcn_xchg_reduce_scatter_end(h2gcn_xchg_t* x, int channel, void* stream_v) 
         hipLaunchKernelGGL(sum_blocks_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)x->rs_recv[channel], pd.own, x->world,
                            x->rank, pd.block_elems, pd.out);
         H2GCN_HIP_TRY(hipGetLastError());
-        // the sum reads this rank's own slot: it must be finished before the slot is staged again -> it becomes part
-        // of what the next begin on this channel waits for
-        const size_t ei = (size_t)channel * x->world + x->rank;
-        if (x->mode != H2GCN_XCHG_COPY_KERNEL) {
-            H2GCN_HIP_TRY(hipEventRecord(x->pulled[ei], stream));
-            x->pulled_valid[ei] = 1;
-        }
+        // the sum reads this rank's own slot: it must be finished before the slot is staged again -> the next begin
+        // on this channel (any mode, any stream) waits for this event
+        H2GCN_HIP_TRY(hipEventRecord(x->summed[channel], stream));
+        x->summed_valid[channel] = 1;
     }
     x->open_channel[channel] = 0;
     return H2GCN_OK;

@@ -11,6 +11,13 @@
 //   ring_k  = expand frontier F = ring_{k-1} through A, subtract ring_0 .. ring_{k-1} (ring_0 = I: sub_diag)
 //   a merged --adj_nhood group such as "0,1" = no expansion, ADD = the member rings.
 //
+// ROW WINDOWS (row-partitioned runs): the expression is evaluated for the rows [row_begin, row_begin +
+// n_rows) only.  Everything indexed by the output row -- F, ADD, SUB, the result -- is then a CSR of that window (local
+// row pointers), while A is the full matrix (indexed by the global ids the frontier names) and `i` in {i} is the global
+// row id.  A rank of a P-way partition thus builds 1/P of every ring from the full A and its own rows of the lower
+// rings: time and memory O(ring / P) instead of the build-everything-then-slice of the reference's host path
+// (_dataset.py:147-157).
+//
 // One workgroup (256 threads; a single wave when level 0 is in global memory) owns one output row at a time (rows are handed out by an atomic ticket, longest-first is not needed:
 // the work per row is bounded by its candidate count).  The row's candidate set lives in a TWO-LEVEL BITMAP:
 //   level 0: one bit per column (n bits) -- in LDS when n <= kLdsBitmapCols, else in a per-workgroup slab of global
@@ -53,7 +60,9 @@ struct Pattern {
 };
 
 struct RingParams {
-    int64_t n;            // rows == columns
+    int64_t n;            // columns (= rows of A)
+    int64_t n_rows;       // rows of the window this launch evaluates
+    int64_t row_begin;    // global id of the window's first row
     Pattern a;            // expansion operand A (self loops already removed); unused when frontier.rowptr == NULL
     Pattern frontier;     // F: rows whose A-rows are united (NULL rowptr = no expansion)
     Pattern add[kMaxPatterns];
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(64 * kSortWaves) void ring_sorted_kernel(const Ring
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int32_t* buf = buf_all[wave];
     const int64_t n_waves = (int64_t)gridDim.x * kSortWaves;
-    for (int64_t i = (int64_t)blockIdx.x * kSortWaves + wave; i < p.n; i += n_waves) {
+    for (int64_t i = (int64_t)blockIdx.x * kSortWaves + wave; i < p.n_rows; i += n_waves) {
         const int64_t c64 = candidate_count(p, i, lane);
         if (c64 > kSortCap) {           // the bitmap kernel serves this row
             if (lane == 0) p.big_rows[atomicAdd(p.big_count, 1u)] = (int32_t)i;
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(64 * kSortWaves) void ring_sorted_kernel(const Ring
             pos += len;
         }
         if (p.add_diag) {
-            if (lane == 0) buf[pos] = (int32_t)i;
+            if (lane == 0) buf[pos] = (int32_t)(p.row_begin + i);
             pos += 1;
         }
         // ---- bitonic sort of the next power of two (padding = INT32_MAX, never a valid column)
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(64 * kSortWaves) void ring_sorted_kernel(const Ring
             if (t < c) {
                 v = buf[t];
                 keep = (t == 0 || buf[t - 1] != v);
-                if (keep && p.sub_diag && v == (int32_t)i) keep = false;
+                if (keep && p.sub_diag && v == (int32_t)(p.row_begin + i)) keep = false;
                 for (int q = 0; keep && q < p.n_sub; ++q) keep = !pattern_row_contains(p.sub[q], i, v);
             }
             const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(kThreads) void ring_kernel(const RingParams p) {
             if (i >= (int64_t)__hip_atomic_load(p.big_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
             i = p.big_rows[i];
         }
-        if (i >= p.n) break;
+        if (i >= p.n_rows) break;
 
         // ---- mark: expansion of the frontier through A, one wave per frontier node, lanes over its neighbours
         if (p.frontier.rowptr) {
@@ -275,14 +284,14 @@ __global__ __launch_bounds__(kThreads) void ring_kernel(const RingParams p) {
             const int64_t b = p.add[q].rowptr[i], e = p.add[q].rowptr[i + 1];
             for (int64_t t = b + tid; t < e; t += kThreads) mark<L0_LDS>(l0, l1, p.add[q].colidx[t]);
         }
-        if (p.add_diag && tid == 0) mark<L0_LDS>(l0, l1, (int32_t)i);
+        if (p.add_diag && tid == 0) mark<L0_LDS>(l0, l1, (int32_t)(p.row_begin + i));
         __syncthreads();
         // ---- subtract
         for (int q = 0; q < p.n_sub; ++q) {
             const int64_t b = p.sub[q].rowptr[i], e = p.sub[q].rowptr[i + 1];
             for (int64_t t = b + tid; t < e; t += kThreads) unmark<L0_LDS>(l0, p.sub[q].colidx[t]);
         }
-        if (p.sub_diag && tid == 0) unmark<L0_LDS>(l0, (int32_t)i);
+        if (p.sub_diag && tid == 0) unmark<L0_LDS>(l0, (int32_t)(p.row_begin + i));
         __syncthreads();
 
         // ---- emit: thread t owns the contiguous level-1 word range [t*per, (t+1)*per) = a contiguous column range
@@ -347,23 +356,32 @@ __global__ __launch_bounds__(kThreads) void ring_kernel(const RingParams p) {
 // deg = row sums of THIS matrix = its row lengths.  `s_table[k]` holds the fp64 scaling of a row with k entries,
 // computed on the host with the reference's own numpy call (np.power) so that the fp64 products -- and the fp32
 // cast sparse2Tensor applies (:528-535) -- are bit-identical; the table depends on nothing but k.
-__global__ void normalize_pattern_kernel(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                         int mode, const double* __restrict__ s_table, float* __restrict__ vals) {
+// Row windows: `rowptr` / `vals` describe n_rows rows; for SYM the length of row j of the WHOLE matrix is col_len[j]
+// (NULL: the pattern is the whole square matrix, lengths come from rowptr).  A row longer than the table raises *flag.
+__global__ void normalize_pattern_kernel(int64_t n_rows, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                         int mode, const double* __restrict__ s_table, int64_t s_table_len,
+                                         const int64_t* __restrict__ col_len, float* __restrict__ vals, int* flag) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t i = wave; i < n; i += n_waves) {
+    bool bad = false;
+    for (int64_t i = wave; i < n_rows; i += n_waves) {
         const int64_t b = rowptr[i], e = rowptr[i + 1];
-        const double si = mode == 0 ? 1.0 : s_table[e - b];
+        double si = 1.0;
+        if (mode != 0) {
+            if (e - b < s_table_len) si = s_table[e - b]; else bad = true;
+        }
         for (int64_t t = b + lane; t < e; t += 64) {
             double v = si * 1.0;
             if (mode == 1) {
                 const int64_t j = colidx[t];
-                v = v * s_table[rowptr[j + 1] - rowptr[j]];
+                const int64_t dj = col_len ? col_len[j] : rowptr[j + 1] - rowptr[j];
+                if (dj < s_table_len) v = v * s_table[dj]; else bad = true;
             }
             vals[t] = (float)v;
         }
     }
+    if (bad) atomicOr(flag, 1);
 }
 
 int check_pattern(const char* what, const int64_t* rp, const int32_t* ci) {
@@ -387,12 +405,14 @@ size_t h2gcn_ring_scratch_bytes(int64_t n) {
     return 64 + big_list + slabs;
 }
 
-static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_t* a_colidx, const int64_t* f_rowptr,
+static int ring_pass(bool fill, int64_t n, int64_t row_begin, int64_t n_rows, const int64_t* a_rowptr, const int32_t* a_colidx, const int64_t* f_rowptr,
                      const int32_t* f_colidx, int n_add, const int64_t* const* add_rowptr, const int32_t* const* add_colidx,
                      int add_diag, int n_sub, const int64_t* const* sub_rowptr, const int32_t* const* sub_colidx, int sub_diag,
                      int64_t* out_rowptr, int32_t* out_colidx, int64_t* nnz_out, void* scratch, size_t scratch_bytes,
                      hipStream_t stream) {
     if (n < 0 || n > 0x7fffffffLL) return fail(H2GCN_ERR_INVALID_ARGUMENT, "n = %lld (column ids are int32)", (long long)n);
+    if (row_begin < 0 || n_rows < 0 || row_begin + n_rows > n)
+        return fail(H2GCN_ERR_INVALID_ARGUMENT, "row window [%lld, %lld) outside 0..%lld", (long long)row_begin, (long long)(row_begin + n_rows), (long long)n);
     if (n_add < 0 || n_add > kMaxPatterns || n_sub < 0 || n_sub > kMaxPatterns)
         return fail(H2GCN_ERR_INVALID_ARGUMENT, "at most %d add / sub patterns", kMaxPatterns);
     if (!out_rowptr) return fail(H2GCN_ERR_INVALID_ARGUMENT, "out_rowptr is NULL");
@@ -404,6 +424,8 @@ static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_
     RingParams p;
     memset(&p, 0, sizeof(p));
     p.n = n;
+    p.n_rows = n_rows;
+    p.row_begin = row_begin;
     p.a = Pattern{a_rowptr, a_colidx};
     p.frontier = Pattern{f_rowptr, f_colidx};
     for (int q = 0; q < n_add; ++q) {
@@ -424,8 +446,8 @@ static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_
     p.l1_words = (p.l0_words + 31) / 32;
     p.ticket = (unsigned int*)scratch;
     p.big_count = (unsigned int*)scratch + 1;
-    if (n == 0) {
-        H2GCN_HIP_TRY(hipMemsetAsync(out_rowptr, 0, sizeof(int64_t), stream));
+    if (n_rows == 0) {
+        if (!fill) H2GCN_HIP_TRY(hipMemsetAsync(out_rowptr, 0, sizeof(int64_t), stream));
         if (nnz_out) *nnz_out = 0;
         return H2GCN_OK;
     }
@@ -438,20 +460,20 @@ static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_
         return fail(H2GCN_ERR_INVALID_ARGUMENT, "ring construction supports up to %d columns (n = %lld)", 150 * 1024 * 256, (long long)n);
     // workgroups per CU the LDS footprint allows (160 KiB per CU, keep some for the static arrays), at most 8
     int per_cu = l0_lds ? (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / (lds_bytes + 2048))) : kSlabsPerCu;
-    unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)cus * per_cu);
+    unsigned grid = (unsigned)std::min<int64_t>(n_rows, (int64_t)cus * per_cu);
     if (!l0_lds) {
         const size_t big_list = ((size_t)n * 4 + 63) / 64 * 64;
         const int64_t n_slabs = (int64_t)((h2gcn_ring_scratch_bytes(n) - 64 - big_list) / ((size_t)p.l0_words * 4));
-        grid = (unsigned)std::min<int64_t>(n, n_slabs);
+        grid = (unsigned)std::min<int64_t>(n_rows, n_slabs);
         p.big_rows = (int32_t*)((char*)scratch + 64);
         p.l0_scratch = (uint32_t*)((char*)scratch + 64 + big_list);
         H2GCN_HIP_TRY(hipMemsetAsync(p.l0_scratch, 0, (size_t)grid * p.l0_words * 4, stream));
     }
     H2GCN_HIP_TRY(hipMemsetAsync(p.ticket, 0, 64, stream));
-    const unsigned sorted_grid = (unsigned)std::min<int64_t>((n + kSortWaves - 1) / kSortWaves, (int64_t)cus * 8);
+    const unsigned sorted_grid = (unsigned)std::min<int64_t>((n_rows + kSortWaves - 1) / kSortWaves, (int64_t)cus * 8);
     p.only_big_rows = l0_lds ? 0 : 1;   // wide graphs: sparse rows go to the sorted-candidate kernel
     if (!fill) {
-        p.counts = out_rowptr + 1;  // counts land in out_rowptr[1..n], the scan below turns them into row pointers
+        p.counts = out_rowptr + 1;  // counts land in out_rowptr[1..n_rows], the scan below turns them into row pointers
         H2GCN_HIP_TRY(hipMemsetAsync(out_rowptr, 0, sizeof(int64_t), stream));
         if (l0_lds) {
             H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)ring_kernel<true, false, kThreadsLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -464,12 +486,12 @@ static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_
         H2GCN_HIP_TRY(hipGetLastError());
         // inclusive scan in place: out_rowptr[1..n]
         size_t tmp_bytes = 0;
-        H2GCN_HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, p.counts, p.counts, (size_t)n, rocprim::plus<int64_t>(), stream));
+        H2GCN_HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, p.counts, p.counts, (size_t)n_rows, rocprim::plus<int64_t>(), stream));
         void* tmp = nullptr;
         H2GCN_HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-        hipError_t e = rocprim::inclusive_scan(tmp, tmp_bytes, p.counts, p.counts, (size_t)n, rocprim::plus<int64_t>(), stream);
+        hipError_t e = rocprim::inclusive_scan(tmp, tmp_bytes, p.counts, p.counts, (size_t)n_rows, rocprim::plus<int64_t>(), stream);
         int64_t total = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(&total, out_rowptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, out_rowptr + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         (void)hipFree(tmp);
         if (e != hipSuccess) return fail(H2GCN_ERR_HIP, "row-pointer scan failed: %s", hipGetErrorString(e));
@@ -490,17 +512,41 @@ static int ring_pass(bool fill, int64_t n, const int64_t* a_rowptr, const int32_
     return H2GCN_OK;
 }
 
+int h2gcn_ring_count_rows(int64_t n, int64_t row_begin, int64_t n_rows, const int64_t* a_rowptr, const int32_t* a_colidx,
+                          const int64_t* f_rowptr, const int32_t* f_colidx, int n_add, const int64_t* const* add_rowptr,
+                          const int32_t* const* add_colidx, int add_diag, int n_sub, const int64_t* const* sub_rowptr,
+                          const int32_t* const* sub_colidx, int sub_diag, int64_t* out_rowptr, int64_t* nnz_out,
+                          void* scratch, size_t scratch_bytes, void* stream) {
+    try {
+        return ring_pass(false, n, row_begin, n_rows, a_rowptr, a_colidx, f_rowptr, f_colidx, n_add, add_rowptr, add_colidx,
+                         add_diag, n_sub, sub_rowptr, sub_colidx, sub_diag, out_rowptr, nullptr, nnz_out, scratch, scratch_bytes,
+                         (hipStream_t)stream);
+    } catch (...) {
+        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in ring_count");
+    }
+}
+
+int h2gcn_ring_fill_rows(int64_t n, int64_t row_begin, int64_t n_rows, const int64_t* a_rowptr, const int32_t* a_colidx,
+                         const int64_t* f_rowptr, const int32_t* f_colidx, int n_add, const int64_t* const* add_rowptr,
+                         const int32_t* const* add_colidx, int add_diag, int n_sub, const int64_t* const* sub_rowptr,
+                         const int32_t* const* sub_colidx, int sub_diag, const int64_t* out_rowptr, int32_t* out_colidx,
+                         void* scratch, size_t scratch_bytes, void* stream) {
+    try {
+        return ring_pass(true, n, row_begin, n_rows, a_rowptr, a_colidx, f_rowptr, f_colidx, n_add, add_rowptr, add_colidx,
+                         add_diag, n_sub, sub_rowptr, sub_colidx, sub_diag, const_cast<int64_t*>(out_rowptr), out_colidx, nullptr,
+                         scratch, scratch_bytes, (hipStream_t)stream);
+    } catch (...) {
+        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in ring_fill");
+    }
+}
+
 int h2gcn_ring_count(int64_t n, const int64_t* a_rowptr, const int32_t* a_colidx, const int64_t* f_rowptr,
                      const int32_t* f_colidx, int n_add, const int64_t* const* add_rowptr,
                      const int32_t* const* add_colidx, int add_diag, int n_sub, const int64_t* const* sub_rowptr,
                      const int32_t* const* sub_colidx, int sub_diag, int64_t* out_rowptr, int64_t* nnz_out,
                      void* scratch, size_t scratch_bytes, void* stream) {
-    try {
-        return ring_pass(false, n, a_rowptr, a_colidx, f_rowptr, f_colidx, n_add, add_rowptr, add_colidx, add_diag, n_sub,
-                         sub_rowptr, sub_colidx, sub_diag, out_rowptr, nullptr, nnz_out, scratch, scratch_bytes, (hipStream_t)stream);
-    } catch (...) {
-        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in ring_count");
-    }
+    return h2gcn_ring_count_rows(n, 0, n, a_rowptr, a_colidx, f_rowptr, f_colidx, n_add, add_rowptr, add_colidx, add_diag, n_sub,
+                                 sub_rowptr, sub_colidx, sub_diag, out_rowptr, nnz_out, scratch, scratch_bytes, stream);
 }
 
 int h2gcn_ring_fill(int64_t n, const int64_t* a_rowptr, const int32_t* a_colidx, const int64_t* f_rowptr,
@@ -508,26 +554,38 @@ int h2gcn_ring_fill(int64_t n, const int64_t* a_rowptr, const int32_t* a_colidx,
                     const int32_t* const* add_colidx, int add_diag, int n_sub, const int64_t* const* sub_rowptr,
                     const int32_t* const* sub_colidx, int sub_diag, const int64_t* out_rowptr, int32_t* out_colidx,
                     void* scratch, size_t scratch_bytes, void* stream) {
-    try {
-        return ring_pass(true, n, a_rowptr, a_colidx, f_rowptr, f_colidx, n_add, add_rowptr, add_colidx, add_diag, n_sub,
-                         sub_rowptr, sub_colidx, sub_diag, const_cast<int64_t*>(out_rowptr), out_colidx, nullptr, scratch,
-                         scratch_bytes, (hipStream_t)stream);
-    } catch (...) {
-        return fail(H2GCN_ERR_INTERNAL, "unexpected exception in ring_fill");
+    return h2gcn_ring_fill_rows(n, 0, n, a_rowptr, a_colidx, f_rowptr, f_colidx, n_add, add_rowptr, add_colidx, add_diag, n_sub,
+                                sub_rowptr, sub_colidx, sub_diag, out_rowptr, out_colidx, scratch, scratch_bytes, stream);
+}
+
+int h2gcn_hop_normalize_rows(int64_t n_rows, const int64_t* rowptr, const int32_t* colidx, int mode, const double* s_table,
+                             int64_t s_table_len, const int64_t* col_len, float* vals, void* stream_v) {
+    if (n_rows < 0 || !rowptr || mode < 0 || mode > 2) return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad arguments to hop_normalize");
+    if (mode != 0 && (!s_table || s_table_len < 1)) return fail(H2GCN_ERR_INVALID_ARGUMENT, "scaling table missing");
+    if (n_rows == 0) return H2GCN_OK;
+    if (!vals || !colidx) return fail(H2GCN_ERR_INVALID_ARGUMENT, "vals/colidx is NULL");
+    hipStream_t stream = (hipStream_t)stream_v;
+    int* flag = nullptr;
+    H2GCN_HIP_TRY(hipMalloc((void**)&flag, sizeof(int)));
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), stream);
+    int h_flag = 0;
+    if (e == hipSuccess) {
+        const unsigned blocks = (unsigned)std::min<int64_t>((n_rows + 3) / 4, 256 * 32);
+        hipLaunchKernelGGL(normalize_pattern_kernel, dim3(blocks), dim3(256), 0, stream, n_rows, rowptr, colidx, mode, s_table,
+                           s_table_len, col_len, vals, flag);
+        e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(flag);
+    if (e != hipSuccess) return fail(H2GCN_ERR_HIP, "hop_normalize: %s", hipGetErrorString(e));
+    if (h_flag) return fail(H2GCN_ERR_INVALID_ARGUMENT, "hop_normalize: a row is longer than the scaling table (s_table_len = %lld)", (long long)s_table_len);
+    return H2GCN_OK;
 }
 
 int h2gcn_hop_normalize(int64_t n, const int64_t* rowptr, const int32_t* colidx, int mode, const double* s_table,
                         int64_t s_table_len, float* vals, void* stream) {
-    if (n < 0 || !rowptr || mode < 0 || mode > 2) return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad arguments to hop_normalize");
-    if (mode != 0 && (!s_table || s_table_len < 1)) return fail(H2GCN_ERR_INVALID_ARGUMENT, "scaling table missing");
-    if (n == 0) return H2GCN_OK;
-    if (!vals || !colidx) return fail(H2GCN_ERR_INVALID_ARGUMENT, "vals/colidx is NULL");
-    const unsigned blocks = (unsigned)std::min<int64_t>((n + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(normalize_pattern_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, rowptr, colidx, mode,
-                       s_table, vals);
-    H2GCN_HIP_TRY(hipGetLastError());
-    return H2GCN_OK;
+    return h2gcn_hop_normalize_rows(n, rowptr, colidx, mode, s_table, s_table_len, nullptr, vals, stream);
 }
 
 }  // extern "C"

@@ -171,24 +171,76 @@ class PlanetoidData:
         return t
 
 
+def sharded_adj_hops(adj_no_self_loops, adj_norm_hops, norm, device, rank: int, world: int, gather=None,
+                     balance: str = "nnz"):
+    """This rank's rows of the ``adj_hops`` operands of a row-partitioned run, built WITHOUT materialising any whole ring:
+
+    phase A  every rank counts the rows of an EQUAL share of the graph (rings below the last one are filled for that
+             share, the last one only counted); the per-row ring lengths are all-gathered (``gather``: list of per-rank
+             int64 ``[K+1, rows]`` tensors -> the same list on every rank; default ``torch.distributed.all_gather``);
+    split    ``balance="nnz"``: prefix-sum-of-work split over rows (work = nonzeros over all hop groups + one unit per
+             group for the output row), ``"rows"``: equal blocks;
+    phase B  every rank builds its final row window of every ring from the whole adjacency pattern and normalises it
+             (SYM needs the row lengths of arbitrary columns: those are the phase-A counts).
+
+    Time and memory per rank are O(rings / P) instead of the O(rings) of building everything and slicing (the scaling
+    wall of the reference's host path, ``_dataset.py:147-157``).  Returns ``(rowptr, colidx, vals, partition)`` with the
+    column ids already in the partition's padded row space."""
+    import torch
+
+    from ..partition import RowPartition
+
+    rp, ci, n = operands.upload_pattern(adj_no_self_loops, device)
+    groups = operands.parse_adj_nhood(adj_norm_hops)
+    max_hop = max(max(g) for g in groups)
+    eq = RowPartition.equal(n, world)
+    mine = operands.ring_row_lengths_window(rp, ci, n, max_hop, eq.rows(rank))
+    if world > 1:
+        if gather is None:
+            import torch.distributed as dist
+
+            def gather(t):
+                padded = torch.zeros((t.shape[0], eq.per), dtype=t.dtype, device=t.device)
+                padded[:, : t.shape[1]] = t
+                outs = [torch.empty_like(padded) for _ in range(world)]
+                dist.all_gather(outs, padded)
+                return [o[:, : eq.rows(q)[1] - eq.rows(q)[0]] for q, o in enumerate(outs)]
+        ring_len = torch.cat(list(gather(mine)), dim=1).contiguous()
+    else:
+        ring_len = mine
+    if balance == "nnz" and world > 1:
+        work = sum(ring_len[g].sum(dim=0) for g in groups) + len(groups)
+        part = RowPartition.balanced(work.cpu().numpy(), world)
+    else:
+        part = eq
+    rps, cis, vas = operands.build_adj_norm_hops_window(rp, ci, n, part.rows(rank), ring_len, adj_norm_hops, norm)
+    cis = [part.to_padded(c) for c in cis]
+    return rps, cis, vas, part
+
+
 def _sharded_tensors(self, device, adj_norm_hops, norm, shard):
+    import os
+
     import torch
 
     from ..hops import HopPlan
-    from ..partition import ShardedHops, block_bounds, slice_csr_rows
+    from ..partition import RowPartition, ShardedHops
 
     rank, world = shard
     n = self.num_samples
-    r0, r1 = block_bounds(n, world, rank)
     t = {"adj": None}
-    t["features"] = self._feature_operand(sp.csr_matrix(self.features)[r0:r1], device, True)
     if adj_norm_hops:
-        rp, ci, va, _ = operands.build_adj_norm_hops_device(self.sparse_adj, adj_norm_hops, norm, device)
-        parts = [slice_csr_rows(rp[k], ci[k], va[k], r0, r1) for k in range(len(rp))]
-        plan = HopPlan([p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts], n, build_transpose=True)
-        t["adj_hops"] = ShardedHops(plan, n, device)
+        rp, ci, va, part = sharded_adj_hops(self.sparse_adj, adj_norm_hops, norm, device, rank, world,
+                                            balance=os.environ.get("H2GCN_PARTITION", "nnz"))
+        n_src = n if part.is_equal else world * part.per
+        plan = HopPlan(rp, ci, va, n_src, build_transpose=True)
+        t["adj_hops"] = ShardedHops(plan, n, device, partition=part)
     else:
+        part = RowPartition.equal(n, world)
         t["adj_hops"] = None
+    r0, r1 = part.rows(rank)
+    t["partition"] = part
+    t["features"] = self._feature_operand(sp.csr_matrix(self.features)[r0:r1], device, True)
     for name in ("y_all", "y_train", "y_val", "y_test"):
         t[name] = torch.from_numpy(np.asarray(getattr(self, name), dtype=np.float32)[r0:r1]).to(device)
     for name in ("train_mask", "val_mask", "test_mask"):

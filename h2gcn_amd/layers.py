@@ -76,20 +76,41 @@ class SparseDropout(torch.nn.Module):
     first dense layer, ``H2GCN.py:250-257``).  The operand is a 1-hop :class:`HopPlan`; its pattern is static, so the
     layer writes the masked values into one persistent buffer (dropped entries as explicit zeros -- the same product as
     ``tf.sparse.retain``) and points the plan at it (``HopPlan.set_values``, which also refreshes the transposed
-    operand the kernel gradient needs).  In eval mode the original values are put back."""
+    operand the kernel gradient needs).
 
-    def __init__(self, drop_prob: float):
+    Eval mode -- a DOCUMENTED DIVERGENCE from the reference: its ``SparseDropout.call(self, input)`` takes no
+    ``training`` argument and ``H2GCN.call`` invokes ``layer(inputs)`` (``H2GCN.py:323``), so Keras never switches it
+    off: the reference also drops sparse feature values during evaluation (its dense ``Dropout`` layers are switched
+    off).  That looks unintended; here the layer is inactive in eval mode by default, like every other dropout.
+    ``at_eval=True`` (CLI ``--sparse_dropout_at_eval``) reproduces the reference's behaviour.
+
+    The plan is shared (``tensors["features"]``): :meth:`restore` puts the original values back; the training step calls
+    it once the backward pass -- which still needs the dropped operand for ``dW = X_drop^T g`` -- is done, so nobody
+    observes dropped values between steps."""
+
+    def __init__(self, drop_prob: float, at_eval: bool = False):
         super().__init__()
         self.drop_prob = float(drop_prob)
+        self.at_eval = bool(at_eval)
         self._buf = None
+        self._plan = None
+
+    def restore(self) -> None:
+        """Point the plan back at its original values (no-op if they are in place)."""
+        plan = self._plan
+        if plan is None:
+            return
+        orig = getattr(plan, "_values_before_dropout", None)
+        if orig is not None and plan.vals[0] is not orig:
+            plan.set_values(0, orig)
 
     def forward(self, plan: HopPlan) -> HopPlan:
         if not isinstance(plan, HopPlan) or plan.n_hops != 1:
             raise TypeError("SparseDropout expects the sparse feature operand as a 1-hop HopPlan")
+        self._plan = plan
         orig = getattr(plan, "_values_before_dropout", None)
-        if not self.training or self.drop_prob <= 0.0:
-            if orig is not None and plan.vals[0] is not orig:
-                plan.set_values(0, orig)
+        if not (self.training or self.at_eval) or self.drop_prob <= 0.0:
+            self.restore()
             return plan
         if orig is None:
             orig = plan._values_before_dropout = plan.vals[0]
@@ -208,7 +229,7 @@ class _FusedPropagation(torch.autograd.Function):
         for k in range(rounds):
             off[k] = pos
             pos += widths[k]
-        buf = torch.empty((n, total), dtype=torch.float32, device=r0.device)
+        buf = concat_buffer(n, total, r0.device)
         buf[:, off[0]:off[0] + w0].copy_(r0)
         for k in range(1, rounds + 1):
             src = buf[:, off[k - 1]:off[k - 1] + widths[k - 1]]
@@ -227,6 +248,15 @@ class _FusedPropagation(torch.autograd.Function):
             g_prev += grad[:, off[k - 1]:off[k - 1] + widths[k - 1]]
             g_k = g_prev
         return g_k, None, None
+
+
+def concat_buffer(n_rows: int, width: int, device) -> torch.Tensor:
+    """``[n_rows, width]`` fp32 view whose row stride is padded to a multiple of 32 floats: every row of the concat
+    buffer starts on a 128-byte cache line, so the gathers of a round touch ``ceil(slot_bytes / 128)`` lines per row
+    wherever the slot's offset allows (hidden sizes that are not multiples of 32, e.g. ``--hidden 100``; free: the
+    padding columns are never read or written)."""
+    ld = (width + 31) // 32 * 32
+    return torch.empty((n_rows, ld), dtype=torch.float32, device=device)[:, :width]
 
 
 def fused_propagation(plan: HopPlan, r0: torch.Tensor, rounds: int) -> torch.Tensor:

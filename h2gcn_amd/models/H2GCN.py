@@ -37,6 +37,9 @@ def add_subparser_args(parser):
     g.add_argument("--no_feature_normalize", action="store_true")
     g.add_argument("--adj_norm", choices=["sym", "rw"], default="sym",
                    help="hop normalisation: sym = D^-1/2 A D^-1/2 (reference default), rw = D^-1 A")
+    g.add_argument("--sparse_dropout_at_eval", action="store_true",
+                   help="reproduce the reference's SparseDropout, which Keras never switches off (it drops sparse feature "
+                        "values during evaluation as well); default: inactive in evaluation like every other dropout")
     g.add_argument("--device", type=str, default="cuda:0", dest="_device")
     g.add_argument("--no_hipgraph", action="store_true", dest="_no_hipgraph",
                    help="run every step eagerly instead of replaying captured hipGraphs")
@@ -88,7 +91,8 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
     dense_features = isinstance(feats, torch.Tensor)  # dense-ish features arrive as a matrix (GEMM path)
     model = H2GCN(layer_setups, input_dim=(feats.shape[1] if dense_features else feats.n_cols),
                   n_hops=(tensors["adj_hops"].n_hops if tensors["adj_hops"] is not None else 0),
-                  sparse_input=not dense_features, l2_regularize_weight=l2_regularize_weight).to(device)
+                  sparse_input=not dense_features, l2_regularize_weight=l2_regularize_weight,
+                  sparse_dropout_at_eval=getattr(args, "sparse_dropout_at_eval", False)).to(device)
     sharded = _is_sharded()
     if sharded:  # replicas must start identical whatever the seeding on each rank (e.g. --random_seed 0)
         for p_ in model.parameters():
@@ -103,6 +107,7 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
         predictions = model(adj, features, adj_hops)
         train_loss = model.loss(predictions, y_train, train_mask)
         train_loss.backward()
+        model.restore_sparse_inputs()   # SparseDropout pointed the shared feature operand at dropped values
         optimizer.step()
         return dict(train_loss=train_loss.detach())
 
@@ -164,6 +169,9 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
         stats = dict(raw)
         stats.update(zip(names, values))
         args.objects["epoch_stats"] = stats
+        hops_obj = args.objects["tensors"].get("adj_hops")
+        if hasattr(hops_obj, "check"):   # the read-back above synchronised: the epoch's exchanges are all accounted for
+            hops_obj.check()
         if not _is_sharded() or dist.get_rank() == 0:
             stats_printer(epoch, stats)
             if getattr(args, "json_stats", False):
@@ -192,6 +200,10 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
             _write_results(args)
         if not _is_sharded() or dist.get_rank() == 0:
             snapshot.write(getattr(args, "checkpoint_dir", None))
+        hops_obj = args.objects["tensors"].get("adj_hops")
+        if hasattr(hops_obj, "close"):   # collective: release IPC-exported exchange buffers (nobody is pulling any more)
+            torch.cuda.synchronize()
+            hops_obj.close()
 
     args.objects.update(model=model, optimizer=optimizer, checkpoint=snapshot, train_step=train_step,
                         test_step=test_step, predict_step=predict_step, embed_step=embed_step)
@@ -241,13 +253,21 @@ def _sharded_steps(model, optimizer):
         correct = (preds.argmax(dim=1) == labels.argmax(dim=1)).to(torch.float32)
         return (correct * m).sum() / global_sum(m.sum())
 
+    def exchange_ok(adj_hops):
+        # a peer that stalled beyond the exchange's time limit (or died) has left NaN-poisoned shards behind: stop here
+        # instead of training on them (reads a host-mapped word per exchange; covers every step issued so far)
+        if hasattr(adj_hops, "check"):
+            adj_hops.check()
+
     def train_step(adj, adj_hops, features, y_train, train_mask, **kwargs):
+        exchange_ok(adj_hops)
         model.train()
         optimizer.zero_grad(set_to_none=True)
         predictions = model(adj, features, adj_hops)
         ce = partial_ce(predictions, y_train, train_mask)
         reg = model.regularization_loss()
         (ce + reg / world).backward()
+        model.restore_sparse_inputs()
         for p in model.parameters():
             if p.grad is not None:
                 dist.all_reduce(p.grad)
@@ -256,6 +276,7 @@ def _sharded_steps(model, optimizer):
 
     @torch.no_grad()
     def test_step(adj, adj_hops, features, y_train, train_mask, y_val, val_mask, y_test, test_mask, **kwargs):
+        exchange_ok(adj_hops)
         model.eval()
         predictions = model(adj, features, adj_hops)
         reg = model.regularization_loss()
@@ -366,7 +387,7 @@ class H2GCN(torch.nn.Module):
     concats (``:339-341``).  Feature widths are tracked statically (keras builds lazily)."""
 
     def __init__(self, layer_setups, input_dim: int, n_hops: int = 2, sparse_input: bool = True,
-                 l2_regularize_weight: float = 0.0):
+                 l2_regularize_weight: float = 0.0, sparse_dropout_at_eval: bool = False):
         super().__init__()
         self.l2 = float(l2_regularize_weight)
         self.layer_objs = torch.nn.ModuleList()
@@ -402,7 +423,8 @@ class H2GCN(torch.nn.Module):
                 self.regularized.append(layer)
                 width = conf["units"]
             elif kind == Layer.DROPOUT:
-                layer = L.SparseDropout(conf["dropout_rate"]) if sparse_input else torch.nn.Dropout(conf["dropout_rate"])
+                layer = (L.SparseDropout(conf["dropout_rate"], at_eval=sparse_dropout_at_eval) if sparse_input
+                         else torch.nn.Dropout(conf["dropout_rate"]))
             elif kind == Layer.SLICE:
                 self.concat_inds.add(ind)
                 layer = L.SliceLayer(**conf)
@@ -483,7 +505,8 @@ class H2GCN(torch.nn.Module):
                 return inputs
             if ind < execute_after:
                 continue
-            if fuse and self.fused is not None and ind == self.fused[0] and not (ind < return_before < self.fused[1]):
+            can_fuse = hasattr(adjhops, "fused_propagation") or (adjhops is not None and adjhops.n_rows == adjhops.n_cols)
+            if fuse and can_fuse and self.fused is not None and ind == self.fused[0] and not (ind < return_before < self.fused[1]):
                 # concat-free propagation: layers fused[0] .. fused[1]-1 in one go (row-sharded runs: the shard's
                 # rows of the same buffer, one exchange per round)
                 _, end, K, tags = self.fused
@@ -512,6 +535,12 @@ class H2GCN(torch.nn.Module):
         if tagged_out is not None:
             tagged_out.update(tagged)
         return inputs
+
+    def restore_sparse_inputs(self) -> None:
+        """Undo what ``SparseDropout`` did to the shared sparse feature operand (after the backward pass)."""
+        for layer in self.layer_objs:
+            if isinstance(layer, L.SparseDropout):
+                layer.restore()
 
     def get_embeddings(self, adj, inputs, adjhops):
         if self.embedding_ind is None:

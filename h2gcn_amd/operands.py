@@ -146,10 +146,14 @@ def _pattern_args(patterns):
     return k, arr_t(*[p[0].data_ptr() for p in patterns]), arr_t(*[p[1].data_ptr() for p in patterns])
 
 
-def ring_set_device(n: int, device, a=None, frontier=None, add=(), add_diag: bool = False, sub=(), sub_diag: bool = False):
+def ring_set_device(n: int, device, a=None, frontier=None, add=(), add_diag: bool = False, sub=(), sub_diag: bool = False,
+                    rows=None, count_only: bool = False):
     """``out[i] = (U_{j in frontier[i]} a[j]  U  U add[i]  U {i}?) \\ (U sub[i] U {i}?)`` over CSR patterns
-    ``(rowptr int64 [n+1], colidx int32 [nnz])`` on ``device``; returns the result pattern with ascending columns.
-    See ``h2gcn_ring_count`` in include/h2gcn_hip.h."""
+    ``(rowptr int64, colidx int32)`` on ``device``; returns the result pattern with ascending columns.
+
+    ``rows = (r0, r1)``: evaluate the window of rows ``[r0, r1)`` only -- ``frontier`` / ``add`` / ``sub`` and the result
+    are then CSRs of that window (``r1 - r0 + 1`` local row pointers), ``a`` stays the whole matrix and ``{i}`` is the
+    global row id (``h2gcn_ring_count_rows``).  ``count_only``: return ``(rowptr, None)`` without filling the columns."""
     import ctypes as C
 
     import torch
@@ -162,18 +166,21 @@ def ring_set_device(n: int, device, a=None, frontier=None, add=(), add_diag: boo
     f_rp, f_ci = frontier if frontier is not None else (None, None)
     n_add, add_rp, add_ci = _pattern_args(list(add))
     n_sub, sub_rp, sub_ci = _pattern_args(list(sub))
+    r0, r1 = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
     with torch.cuda.device(device):
         stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         sb = int(L.h2gcn_ring_scratch_bytes(n))
         scratch = torch.empty(sb, dtype=torch.uint8, device=device)
-        rowptr = torch.empty(n + 1, dtype=torch.int64, device=device)
+        rowptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=device)
         nnz = C.c_int64()
-        common = (n, ptr(a_rp), ptr(a_ci), ptr(f_rp), ptr(f_ci), n_add, add_rp, add_ci, int(add_diag), n_sub, sub_rp, sub_ci,
-                  int(sub_diag))
-        _capi.check(L.h2gcn_ring_count(*common, ptr(rowptr), C.byref(nnz), ptr(scratch), sb, stream))
+        common = (n, r0, r1 - r0, ptr(a_rp), ptr(a_ci), ptr(f_rp), ptr(f_ci), n_add, add_rp, add_ci, int(add_diag), n_sub, sub_rp,
+                  sub_ci, int(sub_diag))
+        _capi.check(L.h2gcn_ring_count_rows(*common, ptr(rowptr), C.byref(nnz), ptr(scratch), sb, stream))
+        if count_only:
+            return rowptr, None
         colidx = torch.empty(nnz.value, dtype=torch.int32, device=device)
         if nnz.value:
-            _capi.check(L.h2gcn_ring_fill(*common, ptr(rowptr), ptr(colidx), ptr(scratch), sb, stream))
+            _capi.check(L.h2gcn_ring_fill_rows(*common, ptr(rowptr), ptr(colidx), ptr(scratch), sb, stream))
     return rowptr, colidx
 
 
@@ -183,21 +190,50 @@ def identity_pattern(n: int, device):
     return (torch.arange(n + 1, dtype=torch.int64, device=device), torch.arange(n, dtype=torch.int32, device=device))
 
 
-def exact_hop_rings_device(rowptr, colidx, n: int, max_hop: int):
+def _window(pattern, r0: int, r1: int):
+    """Rows [r0, r1) of a device CSR pattern as a window CSR (local row pointers)."""
+    rowptr, colidx = pattern
+    lo, hi = int(rowptr[r0]), int(rowptr[r1])
+    return (rowptr[r0:r1 + 1] - lo).contiguous(), colidx[lo:hi].contiguous()
+
+
+def exact_hop_rings_device(rowptr, colidx, n: int, max_hop: int, rows=None, count_last: bool = False):
     """Device version of :func:`exact_hop_rings`: list of CSR patterns ``(rowptr, colidx)``; ring 0 = I.  Like the
-    reference (``_dataset.py:152-153``) the list ends early once reachability stops growing."""
+    reference (``_dataset.py:152-153``) the list ends early once reachability stops growing.
+
+    ``rows = (r0, r1)``: only that row window of every ring (window CSRs; what one rank of a row partition needs --
+    ring k of the window is grown from the whole ``A`` and the window's rows of the lower rings).  The early exit is then
+    left to the caller (it is a property of the whole ring).  ``count_last``: the last ring is only counted
+    (``(rowptr, None)``) -- enough to learn its row lengths."""
     dev = rowptr.device
     a = (rowptr, colidx)
-    rings = [identity_pattern(n, dev)]
+    r0, r1 = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+    eye = (torch_arange(r1 - r0 + 1, dev), torch_arange_i32(r0, r1, dev))
+    rings = [eye]
     for k in range(1, int(max_hop) + 1):
+        only_count = count_last and k == int(max_hop)
         if k == 1:   # bin(I (A + I)) - I: the off-diagonal pattern of A
-            ring = ring_set_device(n, dev, add=[a], sub_diag=True)
+            ring = ring_set_device(n, dev, add=[a if rows is None else _window(a, r0, r1)], sub_diag=True, rows=rows,
+                                   count_only=only_count)
         else:        # expand the frontier ring_{k-1}, drop everything within distance < k
-            ring = ring_set_device(n, dev, a=a, frontier=rings[k - 1], sub=rings[1:k], sub_diag=True)
-        if ring[1].numel() == 0 and k > 1:   # reach did not grow (the reference's edge_sum test; its first ring is
-            break                            # always kept: edge_sum starts at 0, _dataset.py:145-153)
+            ring = ring_set_device(n, dev, a=a, frontier=rings[k - 1], sub=rings[1:k], sub_diag=True, rows=rows,
+                                   count_only=only_count)
+        if rows is None and not only_count and ring[1].numel() == 0 and k > 1:   # reach did not grow (the reference's
+            break                            # edge_sum test; its first ring is always kept: edge_sum starts at 0, :145-153)
         rings.append(ring)
     return rings
+
+
+def torch_arange(m: int, device):
+    import torch
+
+    return torch.arange(m, dtype=torch.int64, device=device)
+
+
+def torch_arange_i32(r0: int, r1: int, device):
+    import torch
+
+    return torch.arange(r0, r1, dtype=torch.int32, device=device)
 
 
 _S_TABLE_CACHE = {}
@@ -221,8 +257,9 @@ def _scaling_table(norm: str, length: int, device):
     return tab
 
 
-def normalize_pattern_device(pattern, n: int, norm: str):
-    """fp32 values of the normalised hop matrix for a square CSR pattern (``h2gcn_hop_normalize``)."""
+def normalize_pattern_device(pattern, n: int, norm: str, col_len=None):
+    """fp32 values of the normalised hop matrix for a CSR pattern (``h2gcn_hop_normalize_rows``).  ``pattern`` is the
+    whole square matrix, or -- with ``col_len`` (int64 ``[n]``: the row lengths of the WHOLE matrix) -- a row window."""
     import ctypes as C
 
     import torch
@@ -239,13 +276,15 @@ def normalize_pattern_device(pattern, n: int, norm: str):
         return vals
     tab = None
     if mode != 0:
-        max_deg = int((rowptr[1:] - rowptr[:-1]).max())
+        max_deg = int(col_len.max()) if col_len is not None else int((rowptr[1:] - rowptr[:-1]).max())
         tab = _scaling_table(norm, max_deg + 1, dev)
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _capi.check(_capi.lib().h2gcn_hop_normalize(n, C.c_void_p(rowptr.data_ptr()), C.c_void_p(colidx.data_ptr()), mode,
-                                                    C.c_void_p(tab.data_ptr()) if tab is not None else None,
-                                                    tab.numel() if tab is not None else 0, C.c_void_p(vals.data_ptr()), stream))
+        _capi.check(_capi.lib().h2gcn_hop_normalize_rows(rowptr.numel() - 1, C.c_void_p(rowptr.data_ptr()), C.c_void_p(colidx.data_ptr()), mode,
+                                                         C.c_void_p(tab.data_ptr()) if tab is not None else None,
+                                                         tab.numel() if tab is not None else 0,
+                                                         C.c_void_p(col_len.data_ptr()) if col_len is not None else None,
+                                                         C.c_void_p(vals.data_ptr()), stream))
     return vals
 
 
@@ -286,3 +325,61 @@ def build_adj_norm_hops_device(adj_no_self_loops, adj_nhood: Sequence[str] = ("1
         cis.append(pat[1])
         vas.append(normalize_pattern_device(pat, n, norm))
     return rps, cis, vas, n
+
+
+def upload_pattern(adj_no_self_loops, device):
+    """scipy adjacency -> ``(rowptr int64, colidx int32, n)`` on ``device`` (canonical: duplicates summed, sorted)."""
+    import torch
+
+    a = sp.csr_matrix(adj_no_self_loops)
+    a.sum_duplicates()
+    a.sort_indices()
+    a.eliminate_zeros()
+    if a.shape[0] != a.shape[1]:
+        raise ValueError(f"adjacency must be square, got {a.shape}")
+    return (torch.from_numpy(a.indptr.astype(np.int64)).to(device), torch.from_numpy(a.indices.astype(np.int32)).to(device),
+            a.shape[0])
+
+
+def ring_row_lengths_window(rowptr, colidx, n: int, max_hop: int, rows):
+    """int64 ``[max_hop + 1, r1 - r0]``: lengths of the window's rows of ring 0 .. ring max_hop (phase A of the sharded
+    build: every rank counts an equal share of the rows; only the last ring is count-only)."""
+    import torch
+
+    rings = exact_hop_rings_device(rowptr, colidx, n, max_hop, rows=rows, count_last=True)
+    return torch.stack([r[0][1:] - r[0][:-1] for r in rings])
+
+
+def build_adj_norm_hops_window(rowptr, colidx, n: int, rows, ring_len, adj_nhood: Sequence[str] = ("1", "2"),
+                               norm: str = SYM_NORMALIZED):
+    """The rows ``[r0, r1)`` of the ``adj_hops`` operands, built from the whole adjacency pattern and nothing else
+    proportional to the whole rings: ``(rowptr_list, colidx_list, vals_list)`` -- window CSRs with GLOBAL column ids.
+    ``ring_len`` = int64 ``[max_hop + 1, n]``, the row lengths of every whole ring (all-gathered phase-A counts): SYM
+    needs ``s[deg_j]`` of arbitrary columns j, and the reference's early exit (a ring with no entries ends the list,
+    ``_dataset.py:152-153``) is a property of the whole ring.  Values are bit-identical to the rows of
+    :func:`build_adj_norm_hops_device`."""
+    groups = parse_adj_nhood(adj_nhood)
+    max_hop = max(max(g) for g in groups)
+    total = ring_len.sum(dim=1)
+    n_rings = 1
+    for k in range(1, max_hop + 1):     # reference: first ring always kept, later ones until reach stops growing
+        if k > 1 and int(total[k]) == 0:
+            break
+        n_rings += 1
+    for g in groups:
+        missing = [i for i in g if i >= n_rings]
+        if missing:
+            raise ValueError(f"hop {missing[0]} requested but the graph's reachability saturates after {n_rings - 1} hops")
+    dev = rowptr.device
+    rings = exact_hop_rings_device(rowptr, colidx, n, max_hop, rows=rows)
+    rps, cis, vas = [], [], []
+    for g in groups:
+        if len(g) == 1:
+            pat = rings[g[0]]
+        else:
+            pat = ring_set_device(n, dev, add=[rings[i] for i in g if i != 0], add_diag=0 in g, rows=rows)
+        col_len = ring_len[g].sum(dim=0).contiguous()     # member rings are disjoint: the group's row lengths add up
+        rps.append(pat[0])
+        cis.append(pat[1])
+        vas.append(normalize_pattern_device(pat, n, norm, col_len=col_len))
+    return rps, cis, vas

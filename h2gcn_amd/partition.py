@@ -11,8 +11,12 @@ bit-for-bit whatever schedule either side picked (feature chunks are kept >= 64 
 Everything after the aggregation in H2GCN (concat, dropout, classifier) is row-local; the backward pass needs the
 mirror-image reduce-scatter of ``dX``.
 
-Rows are split into equal blocks (``ceil(N/P)`` rows, last block shorter or empty) so that the all-gather is a
-single fixed-count collective; the gathered buffer is padded to ``P * ceil(N/P)`` rows and viewed as ``[:N]``.
+Partitioning rule (:class:`RowPartition`): contiguous row blocks, either equal row counts (synthetic graphs: random row
+order balances the nonzeros by itself) or NNZ-BALANCED -- a prefix-sum-of-work split, for real graphs whose degrees are
+power-law and unshuffled (the planetoid / generator files the reference loads, ``_dataset.py:195-305``).  Blocks then
+differ in height; every exchange works on a PADDED row space (``per`` = the tallest block; rank q's rows land at
+``[q * per, q * per + rows_q)`` of the gathered buffer) so that the all-gather stays one fixed-count collective, and a
+shard's column ids are remapped into that space once, when the shard is built (``RowPartition.to_padded``).
 """
 from __future__ import annotations
 
@@ -50,6 +54,71 @@ def block_bounds(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
 
 def rows_per_rank(n_rows: int, world_size: int) -> int:
     return -(-n_rows // world_size)
+
+
+class RowPartition:
+    """Contiguous row blocks ``[bounds[p], bounds[p+1])`` of an ``n``-row operand over ``world`` ranks.
+
+    ``per`` = rows of the tallest block = the fixed shard height of every exchange; the padded row space has
+    ``world * per`` rows and global row ``i`` of rank ``q`` sits at ``q * per + (i - bounds[q])``.  For equal blocks
+    (``RowPartition.equal``) the padded space coincides with the global one (``to_padded`` is the identity)."""
+
+    def __init__(self, bounds):
+        self.bounds = [int(b) for b in bounds]
+        if len(self.bounds) < 2 or self.bounds[0] != 0 or any(b1 < b0 for b0, b1 in zip(self.bounds, self.bounds[1:])):
+            raise ValueError(f"bad partition bounds {self.bounds}")
+        self.world = len(self.bounds) - 1
+        self.n = self.bounds[-1]
+        self.per = max(1, max(b1 - b0 for b0, b1 in zip(self.bounds, self.bounds[1:]))) if self.n else 0
+        self.is_equal = self.bounds == [min(p * rows_per_rank(self.n, self.world), self.n) for p in range(self.world + 1)]
+
+    @classmethod
+    def equal(cls, n_rows: int, world_size: int) -> "RowPartition":
+        per = rows_per_rank(n_rows, world_size)
+        return cls([min(p * per, n_rows) for p in range(world_size + 1)])
+
+    @classmethod
+    def balanced(cls, row_work, world_size: int) -> "RowPartition":
+        """Prefix-sum-of-work split: block p ends at the first row where the running work reaches ``(p+1)/P`` of the
+        total (``row_work``: non-negative per-row cost, e.g. nonzeros over all hops + a constant per row for the output
+        write).  Each block's work exceeds the mean by less than one row's work."""
+        import numpy as np
+
+        w = np.asarray(row_work, dtype=np.float64).reshape(-1)
+        n = w.shape[0]
+        cum = np.cumsum(w)
+        total = float(cum[-1]) if n else 0.0
+        if total <= 0.0:
+            return cls.equal(n, world_size)
+        targets = total * np.arange(1, world_size) / world_size
+        # a block takes the row that crosses its target only if that leaves it closer to the target
+        cut = np.searchsorted(cum, targets, side="left")
+        lo = np.where(cut > 0, cum[np.maximum(cut - 1, 0)], 0.0)
+        take = (cum[np.minimum(cut, n - 1)] - targets) <= (targets - lo)
+        cut = np.minimum(cut + take.astype(np.int64), n)
+        bounds = np.concatenate([[0], np.maximum.accumulate(cut), [n]])
+        return cls(bounds.tolist())
+
+    def rows(self, rank: int) -> Tuple[int, int]:
+        return self.bounds[rank], self.bounds[rank + 1]
+
+    def to_padded(self, colidx: torch.Tensor) -> torch.Tensor:
+        """Global row ids -> positions in the padded row space (int32 in, int32 out; identity for equal blocks)."""
+        if self.is_equal:
+            return colidx
+        b = torch.tensor(self.bounds, dtype=torch.int64, device=colidx.device)
+        c = colidx.to(torch.int64)
+        q = torch.bucketize(c, b[1:], right=True)
+        return (q * self.per + (c - b[q])).to(torch.int32)
+
+    def imbalance(self, row_work) -> float:
+        """max over ranks of the block's work / mean block work."""
+        import numpy as np
+
+        w = np.asarray(row_work, dtype=np.float64).reshape(-1)
+        cum = np.concatenate([[0.0], np.cumsum(w)])
+        per_rank = np.diff(cum[self.bounds])
+        return float(per_rank.max() / max(per_rank.mean(), 1e-300))
 
 
 class EmbeddingAllGather:
@@ -108,12 +177,14 @@ class IpcExchange:
     the current stream wait for the shards.  ``check()`` raises if any device-side wait ever timed out."""
 
     def __init__(self, n_channels: int, slot_bytes: int, device, group: Optional[dist.ProcessGroup] = None,
-                 mode: str = "engine", timeout_ms: int = 10000):
+                 mode: str = "engine", timeout_ms: Optional[int] = None):
         import ctypes as C
 
         from . import _capi
         if mode not in ("engine", "kernel"):
             raise ValueError(f"unknown IPC exchange mode {mode!r}")
+        if timeout_ms is None:   # how long a GPU waits for a peer's shard before it gives up, poisons the block and flags it
+            timeout_ms = int(os.environ.get("H2GCN_XCHG_TIMEOUT_MS", "10000"))
         self._C, self._capi = C, _capi
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -234,12 +305,15 @@ class PipelinedHopAggregation:
     FAST_WIDTHS = (32, 64, 128, 256)
 
     def __init__(self, plan, n_rows_global: int, d: int, n_chunks, device,
-                 group: Optional[dist.ProcessGroup] = None, exchange: str = "allgather"):
+                 group: Optional[dist.ProcessGroup] = None, exchange: str = "allgather",
+                 partition: Optional[RowPartition] = None, ipc_timeout_ms: Optional[int] = None):
         """``n_chunks``: number of equal feature chunks, or an explicit list of chunk widths summing to ``d``
-        (e.g. ``[32, 32, 64]``: a narrow first chunk shortens the un-overlapped head of the exchange, wider later
-        chunks keep the SpMM efficient)."""
+        (e.g. ``[64, 192]``: a narrow first chunk shortens the un-overlapped head of the exchange).
+        ``partition``: the row blocks (default: equal blocks).  With unequal blocks the plan's column ids must already
+        live in the padded row space (``RowPartition.to_padded``; ``plan.n_cols == world * per``)."""
         if exchange not in ("allgather", "p2p", "ipc_engine", "ipc_kernel"):
             raise ValueError(f"unknown exchange {exchange!r}")
+        self.ipc_timeout_ms = ipc_timeout_ms   # None: $H2GCN_XCHG_TIMEOUT_MS, else 10 s
         self._gather = _all_gather_rows_p2p if exchange == "p2p" else _all_gather_rows
         self.exchange = exchange
         self.ipc = None
@@ -262,11 +336,16 @@ class PipelinedHopAggregation:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.n, self.d, self.C = int(n_rows_global), int(d), len(widths)
-        self.per = rows_per_rank(self.n, self.world)
-        self.r0, self.r1 = block_bounds(self.n, self.world, self.rank)
+        self.partition = partition if partition is not None else RowPartition.equal(self.n, self.world)
+        if self.partition.world != self.world or self.partition.n != self.n:
+            raise ValueError(f"partition is {self.partition.world} blocks of {self.partition.n} rows, run has {self.world} ranks / {self.n} rows")
+        self.per = self.partition.per
+        self.r0, self.r1 = self.partition.rows(self.rank)
         self.device = device
-        if plan.n_cols != self.n or plan.n_rows != self.r1 - self.r0:
-            raise ValueError(f"plan is {plan.n_rows} x {plan.n_cols}, expected {self.r1 - self.r0} x {self.n}")
+        #: rows of the gather source the plan addresses: the global rows (equal blocks) or the padded row space
+        self.n_src = self.n if (self.partition.is_equal and plan.n_cols == self.n) else self.world * self.per
+        if plan.n_cols != self.n_src or plan.n_rows != self.r1 - self.r0:
+            raise ValueError(f"plan is {plan.n_rows} x {plan.n_cols}, expected {self.r1 - self.r0} x {self.n_src}")
         self.use_streams = torch.device(device).type == "cuda"  # CPU/gloo (tests): same schedule, no streams
         if self.world > 1:
             # high priority: its event waits / staging must not queue behind the SpMM grid
@@ -279,7 +358,8 @@ class PipelinedHopAggregation:
             if exchange.startswith("ipc_"):
                 if not self.use_streams:
                     raise ValueError("the IPC exchange needs GPU buffers")
-                self.ipc = IpcExchange(self.C, self.per * max(widths) * 4, device, group, mode=exchange[4:])
+                self.ipc = IpcExchange(self.C, self.per * max(widths) * 4, device, group, mode=exchange[4:],
+                                       timeout_ms=self.ipc_timeout_ms)
         #: set to a list to have (start, end) timing-event pairs appended around every SpMM launch
         self.kernel_events = None
 
@@ -291,6 +371,14 @@ class PipelinedHopAggregation:
         if getattr(self, "ipc_rs", None) is not None:
             self.ipc_rs.close()
             self.ipc_rs = None
+
+    def check(self) -> None:
+        """Raise if a device-side wait of this layer's IPC exchanges has ever given up (a peer stalled beyond the time
+        limit or died; the affected blocks were overwritten with NaN).  Reads a host-mapped word: no synchronisation."""
+        if self.ipc is not None:
+            self.ipc.check()
+        if getattr(self, "ipc_rs", None) is not None:
+            self.ipc_rs.check()
 
     def exchange_only(self) -> None:
         """The step's exchange without the SpMM (diagnostics): every chunk of the last staged shard again."""
@@ -335,7 +423,7 @@ class PipelinedHopAggregation:
             for c in range(self.C):
                 self.send[c][:n_local].copy_(x_local[:, cols[c]])
                 self._gather(self.full[c], self.send[c], self.group)
-                self._spmm(self.full[c][: self.n], out[:, :, cols[c]], hops)
+                self._spmm(self.full[c][: self.n_src], out[:, :, cols[c]], hops)
             return out
         if self.ipc is not None:
             # staging + notification of every chunk first (device-side order matters, see exchange.hip), pulls run on
@@ -346,7 +434,7 @@ class PipelinedHopAggregation:
                 self.ipc.pull(c, self.full[c], self.per)
             for c in range(self.C):
                 self.ipc.end(c)
-                self._spmm(self.full[c][: self.n], out[:, :, cols[c]], hops)
+                self._spmm(self.full[c][: self.n_src], out[:, :, cols[c]], hops)
             return out
         main = torch.cuda.current_stream(self.device)
         for c in range(self.C):  # stage chunk by chunk so that the first exchange can start after the first copy
@@ -359,7 +447,7 @@ class PipelinedHopAggregation:
                 self.ready[c].record(self.comm_stream)
         for c in range(self.C):
             main.wait_event(self.ready[c])
-            self._spmm(self.full[c][: self.n], out[:, :, cols[c]], hops)
+            self._spmm(self.full[c][: self.n_src], out[:, :, cols[c]], hops)
         return out
 
 
@@ -407,11 +495,15 @@ def _reduce_scatter_dx(layer: "PipelinedHopAggregation", dx_full: torch.Tensor) 
     """Full-height adjoint contribution ``A_k[rows_p, :]^T dY_p`` ([N, d]) -> this rank's rows of the summed gradient."""
     if layer.world == 1:
         return dx_full
-    padded = torch.zeros((layer.world * layer.per, dx_full.shape[1]), dtype=dx_full.dtype, device=dx_full.device)
-    padded[: layer.n] = dx_full
+    if dx_full.shape[0] == layer.world * layer.per and dx_full.is_contiguous():
+        padded = dx_full          # already the padded row space
+    else:
+        padded = torch.zeros((layer.world * layer.per, dx_full.shape[1]), dtype=dx_full.dtype, device=dx_full.device)
+        padded[: dx_full.shape[0]] = dx_full
     if getattr(layer, "ipc", None) is not None:  # the library's own exchange: pulls + a fixed-order sum, no collective library
         if getattr(layer, "ipc_rs", None) is None:
-            layer.ipc_rs = IpcExchange(1, layer.world * layer.per * layer.d * 4, layer.device, layer.group, mode=layer.exchange[4:])
+            layer.ipc_rs = IpcExchange(1, layer.world * layer.per * layer.d * 4, layer.device, layer.group, mode=layer.exchange[4:],
+                                       timeout_ms=layer.ipc_timeout_ms)
         mine = layer.ipc_rs.reduce_scatter(0, padded, layer.per)
     else:
         mine = _reduce_scatter_rows(padded, layer.per, layer.rank, layer.group)
@@ -461,7 +553,8 @@ class _ShardedFusedPropagation(torch.autograd.Function):
         for k in range(rounds):
             off[k] = pos
             pos += widths[k]
-        buf = torch.empty((n_local, sum(widths)), dtype=torch.float32, device=r0.device)
+        from .layers import concat_buffer
+        buf = concat_buffer(n_local, sum(widths), r0.device)
         buf[:, off[0]:off[0] + w0].copy_(r0)
         for k in range(1, rounds + 1):
             src = buf[:, off[k - 1]:off[k - 1] + widths[k - 1]]
@@ -492,7 +585,7 @@ class ShardedHops:
     aggregates; its backward is the shard adjoint followed by a reduce-scatter."""
 
     def __init__(self, plan, n_global: int, device, group: Optional[dist.ProcessGroup] = None, chunk_cols: int = 64,
-                 max_chunks: int = 4, exchange: Optional[str] = None):
+                 max_chunks: int = 4, exchange: Optional[str] = None, partition: Optional[RowPartition] = None):
         #: "allgather" (RCCL) | "p2p" | "ipc_engine" | "ipc_kernel"; default from $H2GCN_EXCHANGE, else "allgather"
         self.exchange = exchange or os.environ.get("H2GCN_EXCHANGE", "allgather")
         self.plan = plan
@@ -501,6 +594,7 @@ class ShardedHops:
         self.group = group
         self.chunk_cols, self.max_chunks = int(chunk_cols), int(max_chunks)
         self.n_hops, self.n_rows, self.n_cols = plan.n_hops, plan.n_rows, plan.n_cols
+        self.partition = partition
         self._pipes = {}
 
     def pipeline(self, d: int) -> "PipelinedHopAggregation":
@@ -509,8 +603,24 @@ class ShardedHops:
             while chunks * 2 <= self.max_chunks and d % (chunks * 2) == 0 and d // (chunks * 2) >= self.chunk_cols:
                 chunks *= 2
             self._pipes[d] = PipelinedHopAggregation(self.plan, self.n_global, d, chunks, self.device, self.group,
-                                                     exchange=self.exchange if self.device.type == "cuda" or not self.exchange.startswith("ipc_") else "allgather")
+                                                     exchange=self.exchange if self.device.type == "cuda" or not self.exchange.startswith("ipc_") else "allgather",
+                                                     partition=self.partition,
+                                                     # training: a rank may legitimately stall for a long time (first-epoch
+                                                     # module loads, rank 0 writing a checkpoint) -- two minutes by default
+                                                     ipc_timeout_ms=int(os.environ.get("H2GCN_XCHG_TIMEOUT_MS", "120000")))
         return self._pipes[d]
+
+    def check(self) -> None:
+        """Raise if any exchange of any pipeline ever timed out (see :meth:`PipelinedHopAggregation.check`); the step
+        closures of a row-partitioned run call this every step."""
+        for pipe in self._pipes.values():
+            pipe.check()
+
+    def close(self) -> None:
+        """Collective: release the IPC-exported buffers of every pipeline (after a barrier: no peer may still be pulling)."""
+        for d in sorted(self._pipes):
+            self._pipes[d].close()
+        self._pipes = {}
 
     def aggregate(self, x_local: torch.Tensor, hops=None) -> torch.Tensor:
         """``GCNLayer(hops=...)`` on the shard: ``hops`` keeps the listed hop indices (unknown ones are ignored like the

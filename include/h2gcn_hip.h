@@ -260,15 +260,40 @@ int h2gcn_ring_fill(int64_t n, const int64_t* a_rowptr_dev, const int32_t* a_col
                     const int64_t* out_rowptr_dev, int32_t* out_colidx_dev, void* scratch_dev, size_t scratch_bytes,
                     void* stream);
 /*
+ * The same for a ROW WINDOW [row_begin, row_begin + n_rows) -- what one rank of a row-partitioned run needs (SURVEY.md
+ * 8(e)): F, ADD, SUB and the result are CSRs of that window (n_rows + 1 local row pointers each), A is the whole n x n
+ * matrix (the frontier names global ids), {i} is the global row id.  Ring k of the window needs the whole A and the
+ * window's rows of the lower rings only, so each rank builds 1/P of every ring (the reference builds everything on one
+ * host, _dataset.py:147-157).  h2gcn_ring_count / _fill are the window [0, n).
+ */
+int h2gcn_ring_count_rows(int64_t n, int64_t row_begin, int64_t n_rows, const int64_t* a_rowptr_dev, const int32_t* a_colidx_dev,
+                          const int64_t* f_rowptr_dev, const int32_t* f_colidx_dev,
+                          int n_add, const int64_t* const* add_rowptr_dev, const int32_t* const* add_colidx_dev, int add_diag,
+                          int n_sub, const int64_t* const* sub_rowptr_dev, const int32_t* const* sub_colidx_dev, int sub_diag,
+                          int64_t* out_rowptr_dev, int64_t* nnz_out, void* scratch_dev, size_t scratch_bytes, void* stream);
+int h2gcn_ring_fill_rows(int64_t n, int64_t row_begin, int64_t n_rows, const int64_t* a_rowptr_dev, const int32_t* a_colidx_dev,
+                         const int64_t* f_rowptr_dev, const int32_t* f_colidx_dev,
+                         int n_add, const int64_t* const* add_rowptr_dev, const int32_t* const* add_colidx_dev, int add_diag,
+                         int n_sub, const int64_t* const* sub_rowptr_dev, const int32_t* const* sub_colidx_dev, int sub_diag,
+                         const int64_t* out_rowptr_dev, int32_t* out_colidx_dev, void* scratch_dev, size_t scratch_bytes,
+                         void* stream);
+/*
  * Values of a hop matrix given as a square CSR PATTERN (every stored entry is 1, as nhoodSplit produces):
  *   mode 0 ORDINARY: 1;  mode 1 SYM: fp32((s[deg_i] * 1.0) * s[deg_j]);  mode 2 RW: fp32(s[deg_i] * 1.0)
  * with deg = the row lengths of THIS matrix (reference: D = rowsum(A_k) of that hop matrix, :115-123) and
  * s_table[k] = the fp64 scaling of a row with k entries (k^-1/2 resp. k^-1, inf -> 0), supplied by the caller -- the
  * Python front end computes it with the reference's own numpy call, which keeps the fp64 products and the fp32 cast
- * of sparse2Tensor (:528-535) bit-identical to the reference.  s_table_len > max row length.
+ * of sparse2Tensor (:528-535) bit-identical to the reference.  s_table_len > max row length (checked).
  */
 int h2gcn_hop_normalize(int64_t n, const int64_t* rowptr_dev, const int32_t* colidx_dev, int mode,
                         const double* s_table_dev, int64_t s_table_len, float* vals_dev, void* stream);
+/* Row-window form: the pattern holds n_rows rows of the matrix; col_len_dev[j] = length of row j of the WHOLE matrix
+ * (needed by SYM for s[deg_j]; NULL = the pattern is the whole square matrix).  Both calls check every row length
+ * against s_table_len on the device and return H2GCN_ERR_INVALID_ARGUMENT when the table is too short (they
+ * synchronise the stream for that). */
+int h2gcn_hop_normalize_rows(int64_t n_rows, const int64_t* rowptr_dev, const int32_t* colidx_dev, int mode,
+                             const double* s_table_dev, int64_t s_table_len, const int64_t* col_len_dev,
+                             float* vals_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Row-shard exchange between the GPUs of one node (no counterpart in the reference: it is single-process,

@@ -357,7 +357,14 @@ def test_set_values_refreshes_forward_and_adjoint_and_sparse_dropout():
     kept = (v != 0)
     assert 0.5 < kept.float().mean().item() < 0.7
     assert torch.allclose(v[kept], orig_vals[kept] / 0.6)
+    drop.restore()                                                                # what the training step does after backward
+    assert plan.vals[0] is orig_vals
+    drop(plan)
+    assert plan.vals[0] is not orig_vals
     assert torch.equal(drop.eval()(plan).vals[0], orig_vals)                      # eval: original operand again
+    ref_like = SparseDropout(0.4, at_eval=True).eval()                            # the reference never switches it off
+    assert (ref_like(plan).vals[0] == 0).float().mean().item() > 0.3
+    ref_like.restore()
     assert np.abs(plan.spmm(x).cpu().numpy() - og.gcn_layer_f64acc([feats], x.cpu().numpy())).max() <= ATOL
 
 
