@@ -184,6 +184,108 @@ def measure_traffic_live(a, timeout_s=240):
                       "(2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 per step; FETCH_SIZE counts L2 misses, i.e. Infinity-Cache hits too)"}
 
 
+def hbm_resident_leg(timeout_s=420):
+    """BASELINE's metric says "achieved HBM GB/s": on the headline shape X (1.23 GB; 614 MB per column slice) is only
+    2.4-4.8x the 256 MiB Infinity Cache, so part of the delivered gather bytes are cache hits -- and rocprofv3 on
+    gfx950 has no counter on the DRAM side of that cache (TCC_EA0_RDREQ_DRAM counts requests *destined* for local
+    memory, Infinity-Cache hits included; no MALL / HBM-channel counter is exposed: `rocprofv3 --list-avail`).  So the
+    line carries a second, short, labelled leg instead: the SAME kernel on the SAME degree distribution with |V| scaled
+    until X (8.2 GB) and every column slice of it are >= 16x the cache (shape `products_x6`: |V| = 16M, 8e8 nonzeros per
+    hop), where delivered bytes ~= DRAM bytes.  Runs as a child process of this script after the headline has been
+    timed (never inside its timed region)."""
+    import subprocess
+
+    child = [sys.executable, str(ROOT / "bench.py"), "--shape", "products_x6", "--steps", "3", "--warmup", "1",
+             "--no-cpu-baseline", "--no-adjoint", "--no-traffic", "--no-hbm-leg"]
+    try:
+        r = subprocess.run(child, env=dict(os.environ, H2GCN_BENCH_CHILD="1"), capture_output=True, text=True, timeout=timeout_s)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"child exited with {r.returncode}: {r.stderr[-300:]}"}
+        c = json.loads(line[-1])
+        rf = c["roofline"]
+        return {"workload": c["config"]["workload"], "X_bytes": c["config"]["n_rows"] * c["config"]["d"] * 4,
+                "kernel_ms": rf["kernel_ms"], "edges_per_s": c["value"], "achieved_GBps": rf["achieved"], "frac": rf["frac"],
+                "gather_ceiling_GBps": rf.get("gather_ceiling_GBps"), "stream_read_GBps": (rf.get("ceilings") or {}).get("stream_read_GBps"),
+                "achieved_over_gather_ceiling": rf.get("achieved_over_gather_ceiling"),
+                "source": "LIVE child run of `bench.py --shape products_x6 --steps 3` on this box, same kernel and schedule rule; "
+                          "X and each of its column slices are >= 16x the Infinity Cache, so this rate is DRAM-side"}
+    except Exception as e:  # noqa: BLE001 -- a report, never a reason to lose the GPU number
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def dry_exchange(a, world, rank, device, backend):
+    """`--dry-exchange` (N > 1): FIRST-CONTACT check of every exchange form on this node before any big allocation --
+    1 MiB shards, a handful of rounds each, per-candidate GB/s of landed bytes, which candidates fail and why.  Meant to
+    be the first thing run on a multi-GPU box: it exercises the RCCL high-priority stream, the grouped send/recv form
+    and the IPC handle exchange with real peers, and (NCCL_DEBUG=INFO is switched on before the process group starts)
+    makes RCCL print the algorithm / protocol / channel count it picks to stderr."""
+    from h2gcn_amd import HopPlan, synth
+    from h2gcn_amd.partition import PipelinedHopAggregation, RowPartition
+
+    d = a.d or 128
+    per = max(1, (1 << 20) // (4 * d))
+    n = per * world
+    part = RowPartition.equal(n, world)
+    r0, r1 = part.rows(rank)
+    degs = [synth.synth_degrees(n, 8 * n, s, n) for s in (synth.SEED_A1, synth.SEED_A2)]
+    csr = [synth.synth_hop_rows(degs[k], n, (synth.SEED_A1, synth.SEED_A2)[k], r0, r1, device) for k in range(2)]
+    plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n)
+    x_local = synth.synth_features(d, synth.SEED_X, r0, r1, device)
+    hwq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    table, rejected = {}, {}
+
+    def all_ok(flag):
+        t = torch.tensor([1.0 if flag else 0.0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0)
+
+    exchanges = [a.exchange] if a.exchange else os.environ.get("H2GCN_BENCH_EXCHANGES", "allgather,p2p,ipc_engine,ipc_kernel").split(",")
+    for ex in exchanges:
+        for spec in ([a.chunks] if a.chunks else ["1", "2"]):
+            key = f"{ex}/{spec}"
+            if ex == "ipc_engine" and world - 1 > hwq - 2:
+                rejected[key] = f"copy-engine pulls park {world - 1} spin-wait kernels on hardware queues; GPU_MAX_HW_QUEUES = {hwq} leaves {hwq - 2}"
+                continue
+            cand, why = None, None
+            try:
+                cand = PipelinedHopAggregation(plan, n, d, parse_chunks(spec, d), device, exchange=ex, partition=part)
+            except Exception as e:  # noqa: BLE001
+                why = f"construct: {type(e).__name__}: {e}"
+            if not all_ok(cand is not None):
+                rejected[key] = why or "construction failed on another rank"
+                if cand is not None and cand.ipc is not None:
+                    cand.ipc._destroy_local()
+                continue
+            try:
+                cand(x_local)                      # stages the shard and runs one full step (exchange + SpMM)
+                torch.cuda.synchronize()
+                cand.check()
+                dist.barrier()
+                t = time.perf_counter()
+                for _ in range(10):
+                    cand.exchange_only()
+                torch.cuda.synchronize()
+                dist.barrier()
+                ms = (time.perf_counter() - t) / 10 * 1e3
+                cand.check()
+            except Exception as e:  # noqa: BLE001
+                why = f"run: {type(e).__name__}: {e}"
+            if not all_ok(why is None):
+                rejected[key] = why or "failed on another rank"
+            else:
+                landed = (world - 1) * per * d * 4
+                table[key] = {"ms_per_exchange": ms, "landed_GBps_per_rank": landed / (ms * 1e-3) / 1e9}
+            try:
+                cand.close()
+            except Exception:  # noqa: BLE001
+                pass
+    if rank == 0:
+        print(json.dumps({"dry_exchange": table, "rejected": rejected, "n_gpus": world, "shard_bytes": per * d * 4,
+                          "dist_backend": backend, "GPU_MAX_HW_QUEUES": hwq,
+                          "note": "1 MiB shards: latency-dominated rates, a smoke test of every exchange form -- not a bandwidth figure"}))
+
+
 def parse_chunks(spec, d):
     """'2' -> 2 equal chunks; '32+32+64' -> explicit widths."""
     spec = str(spec)
@@ -212,6 +314,10 @@ def main():
     ap.add_argument("--no-probe", action="store_true", help="skip the live gather/copy ceiling probe")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-hbm-leg", action="store_true",
+                    help="skip the HBM-resident leg (products_x6, 3 steps, child process) the default N=1 products line carries")
+    ap.add_argument("--dry-exchange", action="store_true",
+                    help="N > 1: only smoke-test every exchange form with 1 MiB shards and print a table (no big allocation)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,6 +331,8 @@ def main():
         # the exchange pipeline drives up to world + 1 streams (main, exchange / one per peer); HIP multiplexes streams
         # onto GPU_MAX_HW_QUEUES hardware queues (default 4) -- give every stream its own, before the runtime starts
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(world + 2, 4), 12)))
+        if a.dry_exchange:
+            os.environ.setdefault("NCCL_DEBUG", "INFO")   # RCCL prints the algorithm / protocol / channels it picks
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: h2gcn_amd has no CPU fallback")
     if os.environ.get("H2GCN_SHARE_GPU") == "1":  # test mode: several ranks on one GPU (RCCL refuses that -> gloo)
@@ -246,6 +354,12 @@ def main():
     from h2gcn_amd import HopPlan, synth
     from h2gcn_amd.partition import PipelinedHopAggregation, block_bounds
 
+    if a.dry_exchange:
+        if world < 2:
+            raise SystemExit("--dry-exchange needs N > 1 ranks")
+        dry_exchange(a, world, rank, device, backend)
+        dist.destroy_process_group()
+        return
     cfg = synth.SHAPES[a.shape]
     n, d = cfg["n"], (a.d or cfg["d"])
     seeds = (synth.SEED_A1, synth.SEED_A2)
@@ -314,6 +428,10 @@ def main():
                 if isinstance(widths, list) and sum(widths) != d:
                     continue
                 key = f"{ex}/{spec}"
+                hwq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+                if ex == "ipc_engine" and world - 1 > hwq - 2:   # one spin-wait kernel per peer is parked on a hardware queue
+                    rejected[key] = f"copy-engine pulls need {world - 1} hardware queues besides the main and exchange ones; GPU_MAX_HW_QUEUES = {hwq}"
+                    continue
                 cand, why = None, None
                 try:
                     cand = PipelinedHopAggregation(plan, n, d, widths, device, exchange=ex)
@@ -351,7 +469,7 @@ def main():
         # comm-only and compute-only times of the chosen schedule (not part of the metric)
         diagnostics["exchange_only_ms"] = timed_ms(layer.exchange_only, 3)
         diagnostics["spmm_only_ms"] = timed_ms(
-            lambda: [plan.spmm(layer.full[c][:n], out=y[:, :, layer.offsets[c]:layer.offsets[c] + layer.widths[c]])
+            lambda: [plan.spmm(layer.full[c][: layer.n_src], out=y[:, :, layer.offsets[c]:layer.offsets[c] + layer.widths[c]])
                      for c in range(layer.C)], 3)
         for k, v in cands.items():  # collective: release the exported buffers of the schedules not chosen
             if v[1] is not layer:
@@ -474,6 +592,12 @@ def main():
         out["roofline"]["ceilings"] = pr
         if pr.get("gather_GBps"):
             out["roofline"]["achieved_over_gather_ceiling"] = achieved / pr["gather_GBps"]
+    if rank == 0 and world == 1 and a.shape == "products" and not a.no_hbm_leg and os.environ.get("H2GCN_BENCH_CHILD") != "1":
+        del y
+        torch.cuda.empty_cache()
+        leg = hbm_resident_leg()
+        out["roofline"]["hbm_resident"] = leg
+        out["roofline"]["hbm_resident_frac"] = leg.get("frac")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(csr, x_local, d, a.cpu_seconds)

@@ -262,7 +262,7 @@ def _run_bench(world, extra, tmp_path, env_extra=None):
                 env.pop(k, None)
         env.update(env_extra or {})
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--no-cpu-baseline",
-                                       "--no-probe", "--no-traffic"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+                                       "--no-probe", "--no-traffic", "--no-hbm-leg"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
     outs = [p.communicate(timeout=1500) for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[1].decode()[-3000:] for o in outs)
     lines = [l for l in outs[0][0].decode().splitlines() if l.startswith("{")]
@@ -305,6 +305,21 @@ def test_bench_multi_rank_branch_runs_and_matches_one_rank(tmp_path, world):
         for extra in (["--chunks", "2"], ["--chunks", "64+64"], ["--slice-cols", "64"], ["--slice-cols", "128"], ["--slice-cols", "256"]):
             alt = _run_bench(1, ["--shape", "arxiv", "--steps", "1", "--warmup", "1", "--no-adjoint"] + extra, tmp_path)
             assert alt["config"]["y_checksum"] == out["config"]["y_checksum"], extra
+
+
+def test_bench_dry_exchange_mode(tmp_path):
+    """`bench.py --gpus N --dry-exchange`: the first-contact smoke test of every exchange form (1 MiB shards, no big
+    allocation) prints one table with a rate per candidate and the rejected ones with their reasons."""
+    out = _run_bench(2, ["--dry-exchange"], tmp_path, env_extra={"H2GCN_BENCH_EXCHANGES": "allgather,ipc_engine,ipc_kernel"})
+    assert out["n_gpus"] == 2 and out["shard_bytes"] == 1 << 20
+    for ex in ("allgather", "ipc_engine", "ipc_kernel"):
+        for spec in ("1", "2"):
+            row = out["dry_exchange"].get(f"{ex}/{spec}")
+            assert row and row["ms_per_exchange"] > 0 and row["landed_GBps_per_rank"] > 0, (ex, spec, out["rejected"])
+    # copy-engine pulls are refused when the hardware queues cannot hold one parked wait kernel per peer
+    out = _run_bench(2, ["--dry-exchange", "--exchange", "ipc_engine"], tmp_path, env_extra={"GPU_MAX_HW_QUEUES": "2"})
+    assert not out["dry_exchange"] and all("GPU_MAX_HW_QUEUES" in v for v in out["rejected"].values())
+    _keep("bench_shared_gpu_dry_exchange_n2.json", out)
 
 
 def test_bench_two_ranks_products_shape(tmp_path):
