@@ -63,6 +63,7 @@ EXPORTED_SYMBOLS = (
     "h2gcn_xchg_allgather_end",
     "h2gcn_xchg_reduce_scatter_begin",
     "h2gcn_xchg_reduce_scatter_end",
+    "h2gcn_xchg_reset_dependencies",
     "h2gcn_xchg_status",
     "h2gcn_xchg_destroy",
 )
@@ -204,6 +205,8 @@ def lib() -> C.CDLL:
     L.h2gcn_xchg_reduce_scatter_begin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.h2gcn_xchg_reduce_scatter_end.restype = C.c_int
     L.h2gcn_xchg_reduce_scatter_end.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.h2gcn_xchg_reset_dependencies.restype = C.c_int
+    L.h2gcn_xchg_reset_dependencies.argtypes = [C.c_void_p]
     L.h2gcn_xchg_status.restype = C.c_int
     L.h2gcn_xchg_status.argtypes = [C.c_void_p]
     L.h2gcn_xchg_destroy.restype = None

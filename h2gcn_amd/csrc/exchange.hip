@@ -17,6 +17,13 @@
 // every peer is its own link, so P-1 transfers run in parallel and no CU is taken from the SpMM) or ONE copy
 // kernel whose workgroups are split over the peers (CU-driven loads over xGMI).
 //
+// hipGraph replay (copy-kernel mode): nothing the device code needs is baked into a launch -- the sequence number of a
+// channel lives in DEVICE memory (post_seq: bumped by the signal kernel; pull_seq: bumped by the last workgroup of the
+// pull kernel), and every address that depends on its parity (which of the two slots) is computed on the device.  A
+// captured train/eval step therefore replays correctly: each replay advances the counters exactly as an eager call
+// would.  Copy-engine mode keeps host-side sequence numbers (hipMemcpyAsync needs its source address on the host) and
+// cannot be captured.
+//
 // Deadlock freedom: signal(q) is enqueued before any wait(q) of the same rank, and everything enqueued before
 // signal(q) depends only on signals < q of the peers -- induction over (step, channel) order, independent of how
 // HIP maps streams onto hardware queues.  A peer that dies leaves waits that give up after `timeout_ms`.
@@ -66,10 +73,20 @@ struct PeerTable {  // device-resident copy of the peer pointers (kernel argumen
 
 // src [rows, width] (stride ld_src) -> slot [rows_per_rank, width] and own block of `full`; rows beyond `rows`
 // are written as zeros (short last shard).  width % 4 == 0 and 16-B alignment take the float4 path.
+// Sequence number of the step being issued on a channel: copy-kernel mode reads it from device memory (`dev` = the
+// channel's post counter, which still holds the previous step's number until the signal kernel bumps it), copy-engine
+// mode gets it from the host.
+struct SeqRef {
+    const uint32_t* dev;
+    uint32_t host;
+    __device__ __forceinline__ uint32_t next() const { return dev ? __hip_atomic_load(dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : host; }
+};
+
 template <bool VEC4>
 __global__ void stage_kernel(const float* __restrict__ src, int64_t ld_src, int64_t rows, int64_t rows_per_rank,
-                             int width, float* __restrict__ slot, float* __restrict__ own) {
+                             int width, char* data, size_t slot_bytes, int channel, SeqRef seq, float* __restrict__ own) {
     using T = typename std::conditional<VEC4, float4, float>::type;
+    float* __restrict__ slot = reinterpret_cast<float*>(data + ((size_t)channel * 2 + (seq.next() & 1u)) * slot_bytes);
     const int wv = VEC4 ? width / 4 : width;
     const int64_t total = rows_per_rank * wv;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -83,13 +100,22 @@ __global__ void stage_kernel(const float* __restrict__ src, int64_t ld_src, int6
     }
 }
 
+// whole matrix -> this step's slot (reduce-scatter staging in copy-kernel mode; bytes a multiple of 4)
+__global__ void copy_to_slot_kernel(const float* __restrict__ src, size_t n_floats, char* data, size_t slot_bytes, int channel, SeqRef seq) {
+    float* __restrict__ slot = reinterpret_cast<float*>(data + ((size_t)channel * 2 + (seq.next() & 1u)) * slot_bytes);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_floats; i += (size_t)gridDim.x * blockDim.x) slot[i] = src[i];
+}
+
 // "my shard `seq` of `channel` is readable": release everything this device wrote so far to system scope, then
 // store the sequence number into the peers' flag words.
-__global__ void signal_kernel(PeerTable peers, int world, int rank, int channel, uint32_t seq) {
+__global__ void signal_kernel(PeerTable peers, int world, int rank, int channel, SeqRef seq_ref, uint32_t* post_seq_dev) {
     const int q = threadIdx.x;
+    const uint32_t seq = seq_ref.next();
     __threadfence_system();
     if (q < world && q != rank)
         __hip_atomic_store(peers.flags[q] + channel * kMaxWorld + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();   // every lane has read the old counter
+    if (q == 0 && post_seq_dev) __hip_atomic_store(post_seq_dev, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // spin until *flag >= seq (wrap-safe signed difference) or the wall clock (100 MHz) runs out
@@ -122,8 +148,16 @@ __global__ void poison_kernel(const int* err, float* dst, size_t n_floats) {
 
 // out[i] = sum over ranks q = 0 .. world-1 (ascending: a fixed order, the result does not depend on arrival order) of
 // block q, where block `rank` is this rank's own contribution and the others arrived in recv[q]
-__global__ void sum_blocks_kernel(const float* __restrict__ recv, const float* __restrict__ own, int world, int rank,
-                                  size_t block_elems, float* __restrict__ out) {
+__global__ void sum_blocks_kernel(const float* __restrict__ recv, const float* own_host, char* data, size_t slot_bytes,
+                                  int channel, const uint32_t* post_seq_dev, int world, int rank, size_t block_elems,
+                                  float* __restrict__ out) {
+    // this rank's own block sits in the slot of the step that was just posted (copy-kernel mode: parity from the device
+    // counter, already bumped by the signal kernel that precedes this launch on the stream)
+    const float* __restrict__ own = own_host;
+    if (post_seq_dev) {
+        const uint32_t seq = __hip_atomic_load(post_seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        own = reinterpret_cast<const float*>(data + ((size_t)channel * 2 + (seq & 1u)) * slot_bytes) + (size_t)rank * block_elems;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < block_elems; i += (size_t)gridDim.x * blockDim.x) {
         float acc = 0.f;
         for (int q = 0; q < world; ++q) acc += (q == rank) ? own[i] : recv[(size_t)q * block_elems + i];
@@ -133,11 +167,15 @@ __global__ void sum_blocks_kernel(const float* __restrict__ recv, const float* _
 
 // Copy-kernel pulls: block b serves peer slot b / kPullBlocksPerPeer (the peers other than `rank`, in order).
 __global__ __launch_bounds__(kPullThreads) void pull_kernel(PeerTable peers, const uint32_t* my_flags, int world, int rank,
-                                                            int channel, uint32_t seq, size_t slot_off, size_t bytes,
+                                                            int channel, uint32_t* pull_seq_dev, unsigned int* pull_done,
+                                                            size_t slot_bytes, size_t extra_off, size_t bytes,
                                                             char* full, long long timeout_ticks, int* err) {
     const int pi = blockIdx.x / kPullBlocksPerPeer;         // 0 .. world-2
     const int sub = blockIdx.x - pi * kPullBlocksPerPeer;
     const int q = pi < rank ? pi : pi + 1;
+    // the step this launch serves = pulls completed so far on the channel + 1 (device counter: a replayed graph advances it)
+    const uint32_t seq = __hip_atomic_load(pull_seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const size_t slot_off = ((size_t)channel * 2 + (seq & 1u)) * slot_bytes + extra_off;
     __shared__ int ok;
     if (threadIdx.x == 0) ok = wait_flag(my_flags + channel * kMaxWorld + q, seq, timeout_ticks, err) ? 1 : 0;
     __syncthreads();
@@ -145,33 +183,39 @@ __global__ __launch_bounds__(kPullThreads) void pull_kernel(PeerTable peers, con
         float* bad = reinterpret_cast<float*>(full + (size_t)q * bytes);
         const float nan = __int_as_float(0x7fc00000);
         for (size_t j = (size_t)sub * kPullThreads + threadIdx.x; j < bytes / 4; j += (size_t)kPullBlocksPerPeer * kPullThreads) bad[j] = nan;
-        return;
+    } else {
+        // the acquire above ran on one wave; make sure no stale line of the peer's slot (read two steps ago) is
+        // served from this XCD's caches to the other waves
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        const u32x4* __restrict__ s = reinterpret_cast<const u32x4*>(peers.data[q] + slot_off);
+        u32x4* __restrict__ d = reinterpret_cast<u32x4*>(full + (size_t)q * bytes);
+        const size_t n16 = bytes / 16;
+        const size_t stride = (size_t)kPullBlocksPerPeer * kPullThreads;
+        size_t i = (size_t)sub * kPullThreads + threadIdx.x;
+        for (; i + 3 * stride < n16; i += 4 * stride) {  // 4 independent 16-B loads in flight per lane
+            const u32x4 a = __builtin_nontemporal_load(s + i);
+            const u32x4 b = __builtin_nontemporal_load(s + i + stride);
+            const u32x4 c = __builtin_nontemporal_load(s + i + 2 * stride);
+            const u32x4 e = __builtin_nontemporal_load(s + i + 3 * stride);
+            d[i] = a;
+            d[i + stride] = b;
+            d[i + 2 * stride] = c;
+            d[i + 3 * stride] = e;
+        }
+        for (; i < n16; i += stride) d[i] = __builtin_nontemporal_load(s + i);
+        // tail bytes (shards are multiples of 4 bytes)
+        if (sub == 0) {
+            const size_t done = n16 * 16;
+            for (size_t j = done + threadIdx.x * 4; j < bytes; j += kPullThreads * 4)
+                *reinterpret_cast<uint32_t*>(full + (size_t)q * bytes + j) =
+                    *reinterpret_cast<const uint32_t*>(peers.data[q] + slot_off + j);
+        }
     }
-    // the acquire above ran on one wave; make sure no stale line of the peer's slot (read two steps ago) is
-    // served from this XCD's caches to the other waves
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    const u32x4* __restrict__ s = reinterpret_cast<const u32x4*>(peers.data[q] + slot_off);
-    u32x4* __restrict__ d = reinterpret_cast<u32x4*>(full + (size_t)q * bytes);
-    const size_t n16 = bytes / 16;
-    const size_t stride = (size_t)kPullBlocksPerPeer * kPullThreads;
-    size_t i = (size_t)sub * kPullThreads + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {  // 4 independent 16-B loads in flight per lane
-        const u32x4 a = __builtin_nontemporal_load(s + i);
-        const u32x4 b = __builtin_nontemporal_load(s + i + stride);
-        const u32x4 c = __builtin_nontemporal_load(s + i + 2 * stride);
-        const u32x4 e = __builtin_nontemporal_load(s + i + 3 * stride);
-        d[i] = a;
-        d[i + stride] = b;
-        d[i + 2 * stride] = c;
-        d[i + 3 * stride] = e;
-    }
-    for (; i < n16; i += stride) d[i] = __builtin_nontemporal_load(s + i);
-    // tail bytes (shards are multiples of 4 bytes)
-    if (sub == 0) {
-        const size_t done = n16 * 16;
-        for (size_t j = done + threadIdx.x * 4; j < bytes; j += kPullThreads * 4)
-            *reinterpret_cast<uint32_t*>(full + (size_t)q * bytes + j) =
-                *reinterpret_cast<const uint32_t*>(peers.data[q] + slot_off + j);
+    // the LAST workgroup to finish bumps the channel's pull counter (every workgroup read it on entry) and re-arms the ticket
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(pull_done, 1u) == gridDim.x - 1) {
+        __hip_atomic_store(pull_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pull_seq_dev, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -186,6 +230,7 @@ struct h2gcn_xchg {
     char* data = nullptr;       // exported: n_channels * 2 slots
     uint32_t* flags = nullptr;  // exported: [kMaxChannels][kMaxWorld] arrival counters, written by the peers
     int* err = nullptr;         // host-mapped: set by a wait that gave up
+    uint32_t* seq_dev = nullptr;  // copy-kernel mode: [3][kMaxChannels] device counters: post_seq, pull_seq, pull_done
     bool connected = false;
     PeerTable peers;
     std::vector<void*> opened;          // pointers to close with hipIpcCloseMemHandle
@@ -224,22 +269,26 @@ void release(h2gcn_xchg* x) {
     if (x->data) (void)hipFree(x->data);
     if (x->flags) (void)hipFree(x->flags);
     if (x->err) (void)hipHostFree(x->err);
+    if (x->seq_dev) (void)hipFree(x->seq_dev);
     delete x;
 }
 
 // Pull `bytes` from every peer q -- its exported memory at offset `src_off` -- into dst + q * bytes, after the peer has
 // announced sequence number `seq` on `channel`; records this channel's pull events.
-int issue_pulls(h2gcn_xchg* x, int channel, uint32_t seq, size_t src_off, size_t bytes, char* dst) {
+int issue_pulls(h2gcn_xchg* x, int channel, uint32_t seq, size_t extra_off, size_t bytes, char* dst) {
     if (x->mode == H2GCN_XCHG_COPY_KERNEL) {
         hipStream_t cs = x->streams[x->rank];
         H2GCN_HIP_TRY(hipStreamWaitEvent(cs, x->fence[channel], 0));
         hipLaunchKernelGGL(pull_kernel, dim3((x->world - 1) * kPullBlocksPerPeer), dim3(kPullThreads), 0, cs, x->peers,
-                           (const uint32_t*)x->flags, x->world, x->rank, channel, seq, src_off, bytes, dst, x->timeout_ticks, x->err);
+                           (const uint32_t*)x->flags, x->world, x->rank, channel, x->seq_dev + kMaxChannels + channel,
+                           (unsigned int*)(x->seq_dev + 2 * kMaxChannels + channel), x->slot_bytes, extra_off, bytes, dst,
+                           x->timeout_ticks, x->err);
         H2GCN_HIP_TRY(hipGetLastError());
         const size_t ei = (size_t)channel * x->world + x->rank;
         H2GCN_HIP_TRY(hipEventRecord(x->pulled[ei], cs));
         x->pulled_valid[ei] = 1;
     } else {
+        const size_t src_off = ((size_t)channel * 2 + (seq & 1u)) * x->slot_bytes + extra_off;
         for (int shift = 1; shift < x->world; ++shift) {
             const int q = (x->rank + shift) % x->world;  // start with a different peer on every rank
             hipStream_t ps = x->streams[q];
@@ -256,6 +305,11 @@ int issue_pulls(h2gcn_xchg* x, int channel, uint32_t seq, size_t src_off, size_t
         }
     }
     return H2GCN_OK;
+}
+
+// sequence reference handed to the kernels of a step (see SeqRef)
+SeqRef seq_ref(const h2gcn_xchg* x, int channel, uint32_t host_seq) {
+    return SeqRef{x->mode == H2GCN_XCHG_COPY_KERNEL ? x->seq_dev + channel : nullptr, host_seq};
 }
 
 }  // namespace
@@ -311,6 +365,8 @@ int h2gcn_xchg_create(int world, int rank, int n_channels, size_t slot_bytes, in
         H2GCN_HIP_TRY(hipMemset(x->flags, 0, flag_bytes));
         H2GCN_HIP_TRY(hipHostMalloc((void**)&x->err, sizeof(int), hipHostMallocMapped));
         *x->err = 0;
+        H2GCN_HIP_TRY(hipMalloc((void**)&x->seq_dev, sizeof(uint32_t) * 3 * kMaxChannels));
+        H2GCN_HIP_TRY(hipMemset(x->seq_dev, 0, sizeof(uint32_t) * 3 * kMaxChannels));
         H2GCN_HIP_TRY(hipDeviceSynchronize());
         int lo = 0, hi = 0;
         H2GCN_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
@@ -413,10 +469,10 @@ static int allgather_impl(h2gcn_xchg_t* x, int channel, const float* src, int64_
         hipStream_t stream = (hipStream_t)stream_v;
         if (!do_post) {  // second half of a split begin: the pulls of what allgather_post staged and announced
             if (x->world == 1 || bytes == 0) return H2GCN_OK;
-            return issue_pulls(x, channel, x->seq[channel], ((size_t)channel * 2 + (x->seq[channel] & 1u)) * x->slot_bytes, bytes, (char*)full);
+            return issue_pulls(x, channel, x->seq[channel], 0, bytes, (char*)full);
         }
-        const uint32_t seq = ++x->seq[channel];
-        const size_t slot_off = ((size_t)channel * 2 + (seq & 1u)) * x->slot_bytes;
+        const uint32_t seq = ++x->seq[channel];   // host mirror (copy-engine mode; copy-kernel mode counts on the device)
+        const SeqRef sr = seq_ref(x, channel, seq);
         float* own = full + (size_t)x->rank * (size_t)rows_per_rank * width;
 
         // everything enqueued on `stream` so far (e.g. the SpMM still reading `full`) precedes the pulls
@@ -432,20 +488,21 @@ static int allgather_impl(h2gcn_xchg_t* x, int channel, const float* src, int64_
             const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
             if (vec4)
                 hipLaunchKernelGGL(stage_kernel<true>, dim3(blocks), dim3(256), 0, stream, src, ld_src, rows, rows_per_rank,
-                                   (int)width, (float*)(x->data + slot_off), own);
+                                   (int)width, x->data, x->slot_bytes, channel, sr, own);
             else
                 hipLaunchKernelGGL(stage_kernel<false>, dim3(blocks), dim3(256), 0, stream, src, ld_src, rows, rows_per_rank,
-                                   (int)width, (float*)(x->data + slot_off), own);
+                                   (int)width, x->data, x->slot_bytes, channel, sr, own);
             H2GCN_HIP_TRY(hipGetLastError());
         }
         if (x->world > 1) {
-            hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, stream, x->peers, x->world, x->rank, channel, seq);
+            hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, stream, x->peers, x->world, x->rank, channel, sr,
+                               sr.dev ? x->seq_dev + channel : nullptr);
             H2GCN_HIP_TRY(hipGetLastError());
         }
         x->open_channel[channel] = do_pull ? 1 : 3;  // 3 = posted, pulls not issued yet
         if (x->world == 1 || bytes == 0 || !do_pull) return H2GCN_OK;
 
-        return issue_pulls(x, channel, seq, slot_off, bytes, (char*)full);
+        return issue_pulls(x, channel, seq, 0, bytes, (char*)full);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in xchg_allgather_begin");
     }
@@ -510,22 +567,35 @@ int h2gcn_xchg_reduce_scatter_begin(h2gcn_xchg_t* x, int channel, const float* s
             x->rs_recv_bytes[channel] = bytes;
         }
         const uint32_t seq = ++x->seq[channel];
-        const size_t slot_off = ((size_t)channel * 2 + (seq & 1u)) * x->slot_bytes;
+        const SeqRef sr = seq_ref(x, channel, seq);
+        const size_t slot_off = ((size_t)channel * 2 + (seq & 1u)) * x->slot_bytes;   // copy-engine mode only
         H2GCN_HIP_TRY(hipEventRecord(x->fence[channel], stream));
         for (int q = 0; q < x->world; ++q)
             if (x->pulled_valid[(size_t)channel * x->world + q])
                 H2GCN_HIP_TRY(hipStreamWaitEvent(stream, x->pulled[(size_t)channel * x->world + q], 0));
         if (x->summed_valid[channel]) H2GCN_HIP_TRY(hipStreamWaitEvent(stream, x->summed[channel], 0));
-        if (bytes > 0) H2GCN_HIP_TRY(hipMemcpyAsync(x->data + slot_off, src, bytes, hipMemcpyDeviceToDevice, stream));
+        if (bytes > 0) {
+            if (sr.dev) {   // the slot's parity is only known on the device
+                const unsigned blocks = (unsigned)std::min<size_t>((bytes / 4 + 255) / 256, 4096);
+                hipLaunchKernelGGL(copy_to_slot_kernel, dim3(blocks), dim3(256), 0, stream, src, bytes / 4, x->data, x->slot_bytes, channel, sr);
+                H2GCN_HIP_TRY(hipGetLastError());
+            } else {
+                H2GCN_HIP_TRY(hipMemcpyAsync(x->data + slot_off, src, bytes, hipMemcpyDeviceToDevice, stream));
+            }
+        }
         if (x->world > 1) {
-            hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, stream, x->peers, x->world, x->rank, channel, seq);
+            hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, stream, x->peers, x->world, x->rank, channel, sr,
+                               sr.dev ? x->seq_dev + channel : nullptr);
+            H2GCN_HIP_TRY(hipGetLastError());
+        } else if (sr.dev) {   // world 1: nobody to tell, but the device counter still names the slot the sum reads
+            hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, stream, x->peers, 1, 0, channel, sr, x->seq_dev + channel);
             H2GCN_HIP_TRY(hipGetLastError());
         }
         x->open_channel[channel] = 2;
         x->rs_pending[channel] = h2gcn_xchg::RsPending{out, (const float*)(x->data + slot_off + (size_t)x->rank * block), block / 4};
         if (x->world == 1 || block == 0) return H2GCN_OK;
         // every peer's slot holds its whole matrix; this rank needs block `rank` of each
-        return issue_pulls(x, channel, seq, slot_off + (size_t)x->rank * block, block, (char*)x->rs_recv[channel]);
+        return issue_pulls(x, channel, seq, (size_t)x->rank * block, block, (char*)x->rs_recv[channel]);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in xchg_reduce_scatter_begin");
     }
@@ -542,8 +612,9 @@ int h2gcn_xchg_reduce_scatter_end(h2gcn_xchg_t* x, int channel, void* stream_v) 
     const h2gcn_xchg::RsPending& pd = x->rs_pending[channel];
     if (pd.block_elems > 0) {
         const unsigned blocks = (unsigned)std::min<size_t>((pd.block_elems + 255) / 256, 4096);
-        hipLaunchKernelGGL(sum_blocks_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)x->rs_recv[channel], pd.own, x->world,
-                           x->rank, pd.block_elems, pd.out);
+        hipLaunchKernelGGL(sum_blocks_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)x->rs_recv[channel], pd.own, x->data,
+                           x->slot_bytes, channel, x->mode == H2GCN_XCHG_COPY_KERNEL ? (const uint32_t*)(x->seq_dev + channel) : nullptr,
+                           x->world, x->rank, pd.block_elems, pd.out);
         H2GCN_HIP_TRY(hipGetLastError());
         // the sum reads this rank's own slot: it must be finished before the slot is staged again -> the next begin
         // on this channel (any mode, any stream) waits for this event
@@ -551,6 +622,15 @@ int h2gcn_xchg_reduce_scatter_end(h2gcn_xchg_t* x, int channel, void* stream_v) 
         x->summed_valid[channel] = 1;
     }
     x->open_channel[channel] = 0;
+    return H2GCN_OK;
+}
+
+int h2gcn_xchg_reset_dependencies(h2gcn_xchg_t* x) {
+    if (!x) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is NULL");
+    for (char c : x->open_channel)
+        if (c) return fail(H2GCN_ERR_INVALID_ARGUMENT, "a channel is between begin and end");
+    std::fill(x->pulled_valid.begin(), x->pulled_valid.end(), 0);
+    std::fill(x->summed_valid.begin(), x->summed_valid.end(), 0);
     return H2GCN_OK;
 }
 

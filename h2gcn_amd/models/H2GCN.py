@@ -11,6 +11,7 @@ checkpoint per epoch; signac bookkeeping and the attention / experimental layer 
 from __future__ import annotations
 
 import operator
+import os
 
 import torch
 import torch.distributed as dist
@@ -97,7 +98,13 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
     if sharded:  # replicas must start identical whatever the seeding on each rank (e.g. --random_seed 0)
         for p_ in model.parameters():
             dist.broadcast(p_.data, src=0)
-    use_graphs = not getattr(args, "_no_hipgraph", False) and optimizer.lower() == "adam" and not sharded
+    hops_obj = tensors.get("adj_hops")
+    # full-batch steps are replayed as hipGraphs; row-partitioned runs too when every exchange of the step goes through the
+    # library's copy-kernel IPC path (H2GCN_EXCHANGE=ipc_kernel: device-side sequence numbers) -- RCCL / gloo collectives
+    # are not captured here
+    use_graphs = (not getattr(args, "_no_hipgraph", False) and optimizer.lower() == "adam"
+                  and (not sharded or (bool(getattr(hops_obj, "capturable", False))
+                                       and os.environ.get("H2GCN_SHARDED_HIPGRAPH", "1") != "0")))
     optimizer = make_optimizer(optimizer, model.parameters(), lr, capturable=use_graphs)
     snapshot = logger.BestSnapshot()
 
@@ -155,7 +162,8 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
     if sharded:
         train_step, test_step = _sharded_steps(model, optimizer)
     if use_graphs:
-        train_step, test_step = _GraphedSteps(train_step, test_step, optimizer, device).wrap()
+        train_step, test_step = _GraphedSteps(train_step, test_step, optimizer, device,
+                                              prepare=getattr(hops_obj, "prepare_capture", None) if sharded else None).wrap()
 
     stats_printer = logger.EpochStatsPrinter()
     args.objects["statsPrinter"] = stats_printer
@@ -237,21 +245,35 @@ def _sharded_steps(model, optimizer):
       owners (``partition.sharded_hop_spmm``); kernel gradients are summed over ranks (all-reduce), then every
       rank applies the same Adam update -- replicas stay bit-identical."""
     world = dist.get_world_size()
+    mask_sums = {}
 
-    def global_sum(x):
-        x = x.detach().clone()
-        dist.all_reduce(x)
-        return x
+    def sum_over_ranks(vec, adj_hops):
+        """Sum of a small fp32 vector over the ranks: through the library's IPC exchange when the shard's exchanges are
+        capturable (no torch.distributed call inside the step, so it can be replayed as a hipGraph), else RCCL / gloo."""
+        if getattr(adj_hops, "capturable", False):
+            return adj_hops.all_reduce_small(vec.contiguous())
+        vec = vec.detach().clone()
+        dist.all_reduce(vec)
+        return vec
+
+    def global_mask_sum(mask):
+        """sum_global(mask): the masks are static, so this is computed once (eagerly, during the warm-up epochs)."""
+        key = (mask.data_ptr(), mask.numel())
+        if key not in mask_sums:
+            t = mask.to(torch.float32).sum().reshape(1)
+            dist.all_reduce(t)
+            mask_sums[key] = t.reshape(())
+        return mask_sums[key]
 
     def partial_ce(preds, labels, mask):
         m = mask.to(torch.float32)
         ce = -(labels * torch.log_softmax(preds, dim=1)).sum(dim=1)
-        return (ce * m).sum() / global_sum(m.sum())
+        return (ce * m).sum() / global_mask_sum(mask)
 
     def partial_acc(preds, labels, mask):
         m = mask.to(torch.float32)
         correct = (preds.argmax(dim=1) == labels.argmax(dim=1)).to(torch.float32)
-        return (correct * m).sum() / global_sum(m.sum())
+        return (correct * m).sum() / global_mask_sum(mask)
 
     def exchange_ok(adj_hops):
         # a peer that stalled beyond the exchange's time limit (or died) has left NaN-poisoned shards behind: stop here
@@ -268,11 +290,17 @@ def _sharded_steps(model, optimizer):
         reg = model.regularization_loss()
         (ce + reg / world).backward()
         model.restore_sparse_inputs()
-        for p in model.parameters():
-            if p.grad is not None:
-                dist.all_reduce(p.grad)
+        # ONE exchange for every dense-kernel gradient and the loss scalar: flatten, sum over ranks (identical order on
+        # every rank: the replicas stay bit-identical), scatter back
+        params = [p for p in model.parameters() if p.grad is not None]
+        flat = torch.cat([p.grad.reshape(-1) for p in params] + [ce.detach().reshape(1)])
+        total = sum_over_ranks(flat, adj_hops)
+        pos = 0
+        for p in params:
+            p.grad.copy_(total[pos:pos + p.numel()].view_as(p.grad))
+            pos += p.numel()
         optimizer.step()
-        return dict(train_loss=global_sum(ce) + reg.detach())
+        return dict(train_loss=total[pos] + reg.detach())
 
     @torch.no_grad()
     def test_step(adj, adj_hops, features, y_train, train_mask, y_val, val_mask, y_test, test_mask, **kwargs):
@@ -283,7 +311,7 @@ def _sharded_steps(model, optimizer):
         parts = torch.stack([partial_acc(predictions, y_train, train_mask), partial_acc(predictions, y_val, val_mask),
                              partial_acc(predictions, y_test, test_mask), partial_ce(predictions, y_val, val_mask),
                              partial_ce(predictions, y_test, test_mask)])
-        dist.all_reduce(parts)
+        parts = sum_over_ranks(parts, adj_hops)
         return dict(train_acc=parts[0], val_acc=parts[1], test_accuracy=parts[2], val_loss=parts[3] + reg,
                     test_loss=parts[4], monitor=dict())
 
@@ -300,9 +328,11 @@ class _GraphedSteps:
 
     WARMUP = 3
 
-    def __init__(self, train_step, test_step, optimizer, device):
+    def __init__(self, train_step, test_step, optimizer, device, prepare=None):
         self.eager_train, self.eager_test = train_step, test_step
         self.optimizer, self.device = optimizer, device
+        self.prepare = prepare   # called (device idle) right before each capture: row-partitioned runs reset the
+                                 # exchange objects' cross-step event dependencies there
         self.calls = 0
         self.train_graph = self.test_graph = None
         self.train_out = self.test_out = None
@@ -317,12 +347,18 @@ class _GraphedSteps:
         torch.cuda.current_stream(self.device).wait_stream(side)
         self.pending_eager_out = eager_out  # if capture fails below, this epoch's update has already happened
         self.optimizer.zero_grad(set_to_none=True)
+        if self.prepare is not None:
+            self.prepare()
         g_train = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_train):
             train_out = self.eager_train(**tensors)
+        if self.prepare is not None:
+            self.prepare()
         g_test = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_test):
             test_out = self.eager_test(**tensors)
+        if self.prepare is not None:
+            self.prepare()
         self.train_graph, self.test_graph, self.train_out, self.test_out = g_train, g_test, train_out, test_out
         return eager_out
 

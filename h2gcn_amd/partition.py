@@ -275,6 +275,21 @@ class IpcExchange:
     def check(self) -> None:
         self._capi.check(self._capi.lib().h2gcn_xchg_status(self._handle))
 
+    def reset_dependencies(self) -> None:
+        """Forget the events of earlier steps (call with the device idle, right before a hipGraph capture begins: a
+        capturing stream must not wait on events recorded outside its capture)."""
+        self._capi.check(self._capi.lib().h2gcn_xchg_reset_dependencies(self._handle))
+
+    def all_reduce_sum(self, channel: int, flat: torch.Tensor, scratch: torch.Tensor) -> torch.Tensor:
+        """Sum of a small fp32 vector over the ranks WITHOUT a collective library: all-gather the vectors through this
+        exchange (``scratch``: contiguous ``[world, n]``), then add the rows -- every rank adds the same rows in the same
+        order, so the replicas stay bit-identical.  Capturable in a hipGraph (copy-kernel mode), unlike a gloo / host
+        staged all-reduce; used for the dense-kernel gradients and the loss scalars of a row-partitioned step."""
+        n = flat.numel()
+        self.begin(channel, flat.view(1, n), scratch, 1)
+        self.end(channel)
+        return scratch.sum(dim=0)
+
     def close(self) -> None:
         """Collective: synchronises, makes sure no peer is still pulling from this rank, then frees the buffers."""
         h = getattr(self, "_handle", None)
@@ -596,6 +611,8 @@ class ShardedHops:
         self.n_hops, self.n_rows, self.n_cols = plan.n_hops, plan.n_rows, plan.n_cols
         self.partition = partition
         self._pipes = {}
+        self._small = None          # (IpcExchange, scratch) of all_reduce_small
+        self._small_views = {}
 
     def pipeline(self, d: int) -> "PipelinedHopAggregation":
         if d not in self._pipes:
@@ -615,12 +632,51 @@ class ShardedHops:
         closures of a row-partitioned run call this every step."""
         for pipe in self._pipes.values():
             pipe.check()
+        if self._small is not None:
+            self._small[0].check()
+
+    @property
+    def capturable(self) -> bool:
+        """True when a whole training / evaluation step of this shard can be captured into a hipGraph: every exchange
+        goes through the library's copy-kernel IPC path (device-side sequence numbers), none through torch.distributed."""
+        return self.exchange == "ipc_kernel" and self.device.type == "cuda"
+
+    def all_reduce_small(self, flat: torch.Tensor) -> torch.Tensor:
+        """Sum a small contiguous fp32 vector over the ranks through the IPC exchange (see ``IpcExchange.all_reduce_sum``)."""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return flat
+        n = flat.numel()
+        if self._small is None or self._small[1].shape[1] < n:
+            if self._small is not None:
+                self._small[0].close()
+            cap = max(n, 1 << 16)
+            xc = IpcExchange(1, cap * 4, self.device, self.group, mode="kernel",
+                             timeout_ms=int(os.environ.get("H2GCN_XCHG_TIMEOUT_MS", "120000")))
+            self._small = (xc, torch.empty((world, cap), dtype=torch.float32, device=self.device))
+        xc, buf = self._small
+        if buf.shape[1] != n:   # the exchange moves whole rows of the scratch: keep its width == n
+            buf = self._small_views.setdefault(n, torch.empty((world, n), dtype=torch.float32, device=self.device))
+        return xc.all_reduce_sum(0, flat, buf)
+
+    def prepare_capture(self) -> None:
+        """Call (collectively, device idle) right before a hipGraph capture of a step that uses this shard."""
+        torch.cuda.synchronize(self.device)
+        for pipe in self._pipes.values():
+            for xc in (pipe.ipc, getattr(pipe, "ipc_rs", None)):
+                if xc is not None:
+                    xc.reset_dependencies()
+        if self._small is not None:
+            self._small[0].reset_dependencies()
 
     def close(self) -> None:
         """Collective: release the IPC-exported buffers of every pipeline (after a barrier: no peer may still be pulling)."""
         for d in sorted(self._pipes):
             self._pipes[d].close()
         self._pipes = {}
+        if self._small is not None:
+            self._small[0].close()
+            self._small = None
 
     def aggregate(self, x_local: torch.Tensor, hops=None) -> torch.Tensor:
         """``GCNLayer(hops=...)`` on the shard: ``hops`` keeps the listed hop indices (unknown ones are ignored like the

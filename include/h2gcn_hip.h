@@ -362,6 +362,15 @@ int h2gcn_xchg_allgather_end(h2gcn_xchg_t* x, int channel, void* stream);
 int h2gcn_xchg_reduce_scatter_begin(h2gcn_xchg_t* x, int channel, const float* src_dev, int64_t rows_per_rank,
                                     int32_t width, float* out_dev, void* stream);
 int h2gcn_xchg_reduce_scatter_end(h2gcn_xchg_t* x, int channel, void* stream);
+/*
+ * hipGraph capture (H2GCN_XCHG_COPY_KERNEL only): every call above may be issued on a capturing stream -- sequence
+ * numbers and slot parity live in device memory, so a replayed graph advances the protocol exactly like an eager call
+ * (all ranks must replay the same graphs in the same order).  Call h2gcn_xchg_reset_dependencies() right before a
+ * capture begins, with the device idle: the object then forgets the events of earlier (un-captured or other-capture)
+ * steps, which a capturing stream must not wait on; whole graphs are ordered by the stream they are replayed on.
+ * Copy-engine mode cannot be captured (hipMemcpyAsync needs the slot address on the host).
+ */
+int h2gcn_xchg_reset_dependencies(h2gcn_xchg_t* x);
 /* H2GCN_OK, or H2GCN_ERR_EXCHANGE_TIMEOUT if any wait on this object has ever given up (results are then
  * undefined).  Does not synchronise: call after the streams involved have been synchronised. */
 int h2gcn_xchg_status(const h2gcn_xchg_t* x);

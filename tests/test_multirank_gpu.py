@@ -142,6 +142,65 @@ def test_row_partitioned_training_matches_single_process(tmp_path, network, exch
         assert abs(a[k] - b[k]) <= 0.02, (k, a[k], b[k])
 
 
+TRAIN_WORKER_TIMED = r'''
+import json, os, sys, time
+sys.path.insert(0, os.environ["H2GCN_ROOT"])
+import torch
+from h2gcn_amd import run_experiments
+t0 = time.perf_counter()
+args = run_experiments.main(["H2GCN", "planetoid", "--dataset", "ind.cora", "--dataset_path", os.environ["DATA_DIR"],
+                             "--epochs", os.environ["EPOCHS"], "--random_seed", "11", "--network_setup", os.environ["NETWORK"]]
+                            + os.environ.get("EXTRA", "").split())
+torch.cuda.synchronize()
+if int(os.environ.get("RANK", "0")) == 0:
+    stats = {k: float(v) for k, v in args.objects["epoch_stats"].items() if k != "monitor"}
+    stats["seconds"] = time.perf_counter() - t0
+    json.dump(stats, open(os.environ["OUT_FILE"], "w"))
+'''
+
+
+def test_row_partitioned_training_replays_as_hipgraph(tmp_path):
+    """Row-partitioned training with every exchange on the library's copy-kernel IPC path (H2GCN_EXCHANGE=ipc_kernel):
+    the train and evaluation steps -- all-gathers, reduce-scatters, the gradient all-reduce -- are captured into hipGraphs
+    after the warm-up epochs and REPLAYED (sequence numbers and slot parity live in device memory, so a replay advances
+    the protocol).  The replayed trajectory equals the eager one; both track the single-process run."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import load_planetoid_golden
+    from test_entrypoints import _export_fixture
+
+    data_dir = tmp_path / "data"
+    _export_fixture(load_planetoid_golden("cora"), data_dir, "ind.cora")
+    network = "M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO"
+    results, logs = {}, {}
+    for tag, world, extra in (("one", 1, "--no_hipgraph"), ("eager", 2, "--no_hipgraph"), ("replay", 2, "")):
+        port = _free_port()
+        procs = []
+        out_file = tmp_path / f"stats_{tag}.json"
+        for rank in range(world):
+            env = dict(os.environ, H2GCN_ROOT=str(ROOT), DATA_DIR=str(data_dir), OUT_FILE=str(out_file), NETWORK=network,
+                       H2GCN_EXCHANGE="ipc_kernel", EPOCHS="30", EXTRA=extra)
+            if world > 1:
+                env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                           MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1")
+            else:
+                env.pop("WORLD_SIZE", None)
+            procs.append(subprocess.Popen([sys.executable, "-c", TRAIN_WORKER_TIMED], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        results[tag], logs[tag] = json.loads(out_file.read_text()), outs
+    assert not any("capture unavailable" in o for o in logs["replay"]), logs["replay"][0][-2000:]
+    # (not bitwise: the replayed run uses torch's capturable Adam, whose update is arranged differently from the eager one)
+    for k in ("train_loss", "val_loss", "test_loss"):
+        assert abs(results["eager"][k] - results["replay"][k]) <= 2e-4, (k, results["eager"][k], results["replay"][k])
+    for k in ("train_acc", "val_acc", "test_accuracy"):
+        assert abs(results["eager"][k] - results["replay"][k]) <= 0.01, (k, results["eager"][k], results["replay"][k])
+    for k in ("train_loss", "val_loss", "test_loss"):
+        assert abs(results["one"][k] - results["replay"][k]) <= 2e-3, (k, results["one"][k], results["replay"][k])
+    _keep("sharded_training_hipgraph_replay.json", {t: results[t] for t in results})
+    print(f"2 ranks on one GPU, 30 epochs of Cora H2GCN-2: eager {results['eager']['seconds']:.2f} s, replayed {results['replay']['seconds']:.2f} s")
+
+
 IPC_WORKER = r"""
 import os, sys
 import numpy as np, torch, torch.distributed as dist
