@@ -9,9 +9,9 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-probe --no-traffic "$@" > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-probe --no-traffic --no-hbm-leg "$@" > "$OUT/bench_trace.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-probe --no-traffic --no-adjoint --steps 3 --warmup 1 "$@" > "$OUT/bench_pmc_$C.log" 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-probe --no-traffic --no-hbm-leg --no-adjoint --steps 3 --warmup 1 "$@" > "$OUT/bench_pmc_$C.log" 2>&1
 done
 # calibration of the read counter on a known byte count: random 512 B row gathers (tools/gather_probe); PROBE=1 only
 [ "${PROBE:-0}" = 1 ] && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_probe" -o probe -- "$ROOT/tools/gather_probe" > "$OUT/probe_pmc.log" 2>&1

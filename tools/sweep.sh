@@ -1,20 +1,12 @@
 #!/bin/bash
-# tools/sweep.sh <outfile> -- one bench line per tuning point (GPU box)
-OUT=$1; : > $OUT
-run() { echo "## $*" >> $OUT; timeout 300 python bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({k:d[k] for k in ('value','ms_per_step')}|{'kernel_ms':d['roofline']['kernel_ms'],'frac':d['roofline']['frac']}))" >> $OUT 2>&1; }
-run --slice-cols 128
-run --slice-cols 64
-run --slice-cols 32
-run --slice-cols 0
-run --slice-cols 128 --chunks 2
-run --slice-cols 128 --chunks 4
-run --variant 1
-run --slice-cols 64 --rows-per-wave 1
-run --slice-cols 64 --rows-per-wave 2
-run --slice-cols 64 --long-row-threshold 256
-run --shape arxiv
-run --d 64
-run --d 64 --slice-cols 32
-run --d 256
-run --d 256 --slice-cols 64
-cat $OUT
+# tools/sweep.sh <outfile> "<bench args>" ["<bench args>" ...] -- one condensed bench line per argument set (GPU box):
+# schedule, forward / adjoint kernel time and roofline fraction.  H2GCN_HIP_LIBRARY may point at an alternative build.
+#   tools/sweep.sh gpurun_out/s.txt "" "--d 100" "--shape arxiv --d 1433" "--shape lowdeg"
+OUT=$1; shift; : > "$OUT"
+for ARGS in "$@"; do
+  echo "## $ARGS" >> "$OUT"
+  timeout 900 python bench.py --no-cpu-baseline --no-probe --no-traffic --no-hbm-leg --steps 8 --warmup 2 $ARGS 2>>"$OUT.err" | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; a=d.get('adjoint',{})
+print(json.dumps({'sched':d['config'].get('schedule'),'kernel_ms':round(r['kernel_ms'],3),'frac':round(r['frac'],4),'adjoint_ms':round(a.get('kernel_ms',0),3),'adjoint_frac':round(a.get('frac',0),4)}))" >> "$OUT" 2>&1
+done
+cat "$OUT"
