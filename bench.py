@@ -314,6 +314,8 @@ def main():
     ap.add_argument("--no-probe", action="store_true", help="skip the live gather/copy ceiling probe")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--pad-rows", action="store_true",
+                    help="give X a row stride padded to 32 floats (every row starts on a 128-byte line), as the model's concat buffer has")
     ap.add_argument("--no-hbm-leg", action="store_true",
                     help="skip the HBM-resident leg (products_x6, 3 steps, child process) the default N=1 products line carries")
     ap.add_argument("--dry-exchange", action="store_true",
@@ -371,6 +373,10 @@ def main():
                    variant=a.variant, long_row_threshold=a.long_row_threshold, rows_per_wave=a.rows_per_wave,
                    slice_cols=a.slice_cols, build_transpose=not a.no_adjoint)
     x_local = synth.synth_features(d, synth.SEED_X, r0, r1, device)
+    if a.pad_rows:
+        padded = torch.zeros((r1 - r0, (d + 31) // 32 * 32), dtype=torch.float32, device=device)
+        padded[:, :d] = x_local
+        x_local = padded[:, :d]
     y = torch.empty((r1 - r0, 2, d), dtype=torch.float32, device=device)
     nnz_local = plan.nnz
     nnz_t = torch.tensor(nnz_local, dtype=torch.int64, device=device)
@@ -533,7 +539,7 @@ def main():
             "parallelism": f"row-partition x{world}" + (f", exchange of X per step: {exchange}" if world > 1 else ""),
             "kernel_variant": a.variant, "feature_chunks": chunk_label, "dist_backend": backend,
             "diagnostics": diagnostics, "slice_cols": a.slice_cols or "auto", "y_checksum": y_checksum,
-            "schedule": plan.schedule(layer.widths[0]),
+            "schedule": plan.schedule(layer.widths[0], ld_src=x_local.stride(0) if world == 1 else None),
             "t_fused_median_ms": kern_ms_median,
             "edges_per_s_from_median_kernel_time": sum(nnz_local) / (kern_ms_median * 1e-3),
         },

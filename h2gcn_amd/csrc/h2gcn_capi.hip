@@ -185,12 +185,13 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 //   * d >= 64: only the widths whose lane geometry yields the canonical summation tree (64 / 128 / 256 columns, see
 //     spmm_kernels.hip.h) -- the largest one that divides d, capped so that the gather working set of one slice
 //     (n_src_rows * slice * 4 B) is friendlier to the 256 MiB Infinity Cache when the whole operand is far beyond it;
-//     widths none of them divides (d = 96, 100, 200 ...): one masked slice of the next power of two up to 256 columns,
-//     slices of 128 beyond that (the last one masked);
+//     widths none of them divides (d = 96, 100, 200 ...): one masked slice of the next power of two up to 256 columns
+//     (narrower slices of rows that do not start on a cache line fetch every boundary line twice), the widest slice
+//     beyond that; 64-column slices when every row starts on a line and the operand is far beyond the caches;
 //   * d < 64: narrow slices of 32 / 16 columns (8 / 16 gathered rows per load instruction; their own, wider tree --
 //     no feature chunking ever goes below 64 columns, so this is not observable across partitions).
 // `forced` > 0 (plan option / scratch layout) overrides the heuristic.
-int pick_slice_cols(int d, int64_t n_src_rows, int forced, double avg_segment_nnz) {
+int pick_slice_cols(int d, int64_t n_src_rows, int forced, double avg_segment_nnz, bool rows_line_aligned = false) {
     if (forced > 0) return forced;
     if (d < 64) {
         if (d % 32 == 0) return 32;
@@ -207,6 +208,14 @@ int pick_slice_cols(int d, int64_t n_src_rows, int forced, double avg_segment_nn
         // segment: only worth it when segments are long enough to amortise that, and never below 64 columns
         if (w > 64 && avg_segment_nnz >= 16.0 && slice_bytes > 768.0 * 1024 * 1024 && d % (w / 2) == 0) continue;
         return w;
+    }
+    if (rows_line_aligned && d % 4 == 0 && avg_segment_nnz >= 16.0 && (double)n_src_rows * d * 4.0 >= 512.0 * 1024 * 1024) {
+        // every row starts on a cache line, so 64-column slices are line-aligned too (no boundary line is fetched twice):
+        // the cache-sized slices of the dividing case, in place, the last one masked (d = 200: what the scratch copy buys
+        // for unaligned rows -- 0.69 -> 0.78 -- without the copy: 0.80; d = 100: 0.67 -> 0.70; d = 300: 0.84).  Not for
+        // widths that are not multiples of 4: the tail lane's overlapping float4 would cross into the previous slice's
+        // line (d = 130: 0.62 in place vs 0.69 through the zero-padded copy)
+        return 64;
     }
     if (d > 256) {
         // many masked-at-the-end slices (raw feature widths: 1433, 3703): every slice pays one pass over the row pointers
@@ -229,6 +238,7 @@ struct LaunchShape {
     double avg;             // nonzeros per (row, hop) segment
     int64_t ld_src;
     int d;
+    bool src_line_aligned;  // every gathered row starts on a 128-byte line: base pointer and row stride (and hop offsets)
 };
 
 // Slice width of the slice-major scratch copy this launch should gather from (see repack_slice_major_kernel);
@@ -247,7 +257,7 @@ int scratch_slice_cols(const h2gcn_plan* plan, const LaunchShape& sh) {
         const int w = pick_slice_cols(d, sh.n_src, plan->slice_cols, sh.avg);
         return (w == 64 || w == 128) && d % w == 0 && w < d ? w : 0;
     }
-    if ((sh.ld_src * 4) % 128 != 0 && d > (sh.adjoint ? 256 : 128) && sh.avg >= 16.0 && (plan->slice_cols == 0 || plan->slice_cols == 64)) {
+    if ((!sh.src_line_aligned || d % 4 != 0) && d > (sh.adjoint ? 256 : 128) && sh.avg >= 16.0 && (plan->slice_cols == 0 || plan->slice_cols == 64)) {
         // rows that are not cache-line aligned and wider than one 128-column slice: line-aligned, cache-sized 64-column
         // blocks (forward, including the copy: d = 132: +4 %, 200: +8 %, 300: +30 %; d = 100 gains nothing: two blocks fetch
         // the same 512 B per edge as the unaligned row and pay a second index pass).  Adjoint: its one masked slice of 256
@@ -272,14 +282,14 @@ struct Schedule {
 // The launch-time decisions (also reported by h2gcn_plan_schedule).  `exact_ok`: the float4 kernels can serve the
 // launch (d >= 4; narrower rows take the generic column-tiled kernel).
 Schedule decide(int variant, bool exact_ok, int d, int rows_per_wave, int n_sel, int forced_slice, int64_t n_src_rows,
-                double avg_segment_nnz) {
+                double avg_segment_nnz, bool rows_line_aligned = false) {
     Schedule sc;
     // index prefetch across segments: pays on short segments (+4 % at mean degree 4), costs ~0.4 % on long ones;
     // variant 2 forces it, variant 3 forbids it (bitwise-identical results either way)
     if (variant == 4) variant = 0;
     sc.pipe = (variant == 2 || (variant == 0 && avg_segment_nnz < 16.0)) && rows_per_wave * n_sel <= 32;
     sc.scalar128 = exact_ok && variant == 1 && d == 128 && forced_slice == 0;  // variant 1 only exists for d = 128
-    sc.slice = (exact_ok && !sc.scalar128) ? pick_slice_cols(d, n_src_rows, forced_slice, avg_segment_nnz) : 0;
+    sc.slice = (exact_ok && !sc.scalar128) ? pick_slice_cols(d, n_src_rows, forced_slice, avg_segment_nnz, rows_line_aligned) : 0;
     sc.exact = sc.slice > 0 || sc.scalar128;
     // short segments: one lane group per segment (G segments of a wave in flight at once) -- slices of 64 / 128 columns;
     // variant 5 forces it, variants 2 / 3 keep the wave-per-segment walk with / without the index prefetch
@@ -291,10 +301,11 @@ Schedule decide(int variant, bool exact_ok, int d, int rows_per_wave, int n_sel,
 
 template <bool SUM>
 int launch(LaunchParams& p, int variant, bool off32, int forced_slice, int64_t n_src_rows, double avg_segment_nnz,
-           hipStream_t stream) {
+           bool rows_line_aligned, hipStream_t stream) {
     using namespace h2gcn;
     const bool exact_ok = p.d >= 4;
-    const Schedule sc = decide(variant, exact_ok, p.d, p.rows_per_wave, p.n_sel, forced_slice, n_src_rows, avg_segment_nnz);
+    const Schedule sc = decide(variant, exact_ok, p.d, p.rows_per_wave, p.n_sel, forced_slice, n_src_rows, avg_segment_nnz,
+                               rows_line_aligned);
     // general store (bias / ReLU epilogue, element-wise tail of a width that is not a multiple of 4): dedicated instantiations
     const bool gen = p.d % 4 != 0 || p.bias != nullptr || p.relu != 0;
     // short-row kernels: shallow fallback batches (more waves per SIMD) once the gather source is far beyond the caches
@@ -606,6 +617,11 @@ int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t*
 
 namespace {
 // hop selection -> LaunchShape (src_vec_ok / ld_src / d are filled in by the caller)
+// every gathered row starts on a 128-byte cache line
+bool line_aligned(const float* src, int64_t ld_src, int64_t ld_src_hop, int n_sel, bool adjoint) {
+    return (reinterpret_cast<uintptr_t>(src) & 127u) == 0 && (ld_src * 4) % 128 == 0 && (!adjoint || n_sel <= 1 || (ld_src_hop * 4) % 128 == 0);
+}
+
 LaunchShape shape_of(const h2gcn_plan* plan, uint32_t mask, bool adjoint) {
     LaunchShape sh;
     memset(&sh, 0, sizeof(sh));
@@ -632,8 +648,10 @@ int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint
     LaunchShape sh = shape_of(plan, mask, adjoint != 0);
     sh.ld_src = ld_src;
     sh.d = d;
+    sh.src_line_aligned = (ld_src * 4) % 128 == 0 && (!adjoint || sh.n_sel <= 1 || (d * 4) % 128 == 0);  // aligned base assumed
     const int rs = scratch_slice_cols(plan, sh);
-    const Schedule sc = decide(plan->variant, d >= 4, d, plan->rows_per_wave, sh.n_sel, rs > 0 ? rs : plan->slice_cols, sh.n_src, sh.avg);
+    const Schedule sc = decide(plan->variant, d >= 4, d, plan->rows_per_wave, sh.n_sel, rs > 0 ? rs : plan->slice_cols, sh.n_src, sh.avg,
+                               rs > 0 || sh.src_line_aligned);
     const int w = sc.exact ? (sc.slice > 0 ? sc.slice : 128) : d;
     if (slice_cols) *slice_cols = w;
     if (n_slices) *n_slices = sc.exact ? (d + w - 1) / w : 1;
@@ -649,8 +667,7 @@ size_t h2gcn_spmm_workspace_bytes(const h2gcn_plan_t* plan, uint32_t hop_mask, i
     uint32_t mask;
     if (resolve_mask(plan, hop_mask, &mask) != H2GCN_OK) return 0;
     LaunchShape sh = shape_of(plan, mask, adjoint != 0);
-    (void)src_dev;
-    (void)ld_src_hop;
+    sh.src_line_aligned = line_aligned(src_dev, ld_src, ld_src_hop, sh.n_sel, adjoint != 0);
     sh.ld_src = ld_src;
     sh.d = d;
     return scratch_bytes(sh, scratch_slice_cols(plan, sh));
@@ -727,13 +744,14 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
         int forced_slice = plan->slice_cols;
         sh.ld_src = ldx;
         sh.d = d;
+        sh.src_line_aligned = line_aligned(X, ldx, 0, s, false);
         const int rs = (lo.workspace_dev && aligned16(lo.workspace_dev)) ? scratch_slice_cols(plan, sh) : 0;
         if (rs > 0 && lo.workspace_bytes >= scratch_bytes(sh, rs)) {
             use_scratch(p, sh, rs, 0, lo.workspace_dev, (hipStream_t)stream_v, &off32);
             H2GCN_HIP_TRY(hipGetLastError());
             forced_slice = rs;
         }
-        return launch<false>(p, plan->variant, off32, forced_slice, plan->n_cols, sh.avg, (hipStream_t)stream_v);
+        return launch<false>(p, plan->variant, off32, forced_slice, plan->n_cols, sh.avg, sh.src_line_aligned, (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_opts_f32");
     }
@@ -796,13 +814,14 @@ int h2gcn_spmm_hops_T_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, cons
         int forced_slice = plan->slice_cols;
         sh.ld_src = ldg_row;
         sh.d = d;
+        sh.src_line_aligned = line_aligned(dY, ldg_row, ldg_hop, s, true);
         const int rs = (lo.workspace_dev && aligned16(lo.workspace_dev) && plan->n_rows > 0) ? scratch_slice_cols(plan, sh) : 0;
         if (rs > 0 && lo.workspace_bytes >= scratch_bytes(sh, rs)) {
             use_scratch(p, sh, rs, ldg_hop, lo.workspace_dev, (hipStream_t)stream_v, &off32);
             H2GCN_HIP_TRY(hipGetLastError());
             forced_slice = rs;
         }
-        return launch<true>(p, plan->variant, off32, forced_slice, plan->n_rows, sh.avg, (hipStream_t)stream_v);
+        return launch<true>(p, plan->variant, off32, forced_slice, plan->n_rows, sh.avg, sh.src_line_aligned, (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_T_f32");
     }

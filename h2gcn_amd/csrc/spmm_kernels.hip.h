@@ -59,6 +59,12 @@ constexpr int kMinWavesPerSimd = H2GCN_MIN_WAVES;
 #define H2GCN_SHORT_FB4_MIN_WAVES 7
 #endif  // ... of the forward short-row kernels with shallow fallback batches (memory-resident operands: occupancy buys
         // bandwidth; fits without spilling -- the adjoint ones would spill and stay at 6)
+#ifndef H2GCN_MAIN_MAXB
+#define H2GCN_MAIN_MAXB 8
+#endif  // deepest load batch of the bandwidth kernels (8 x 16 B per lane in flight)
+#ifndef H2GCN_WIDE_MAXB
+#define H2GCN_WIDE_MAXB H2GCN_MAIN_MAXB
+#endif  // deepest load batch of the plain walk of the 128 / 256-column slices
 #ifndef H2GCN_WIDE_MIN_WAVES
 #define H2GCN_WIDE_MIN_WAVES H2GCN_MIN_WAVES
 #endif  // ... of the 128 / 256-column slices, whose lanes keep 2 / 4 partials of the canonical tree
@@ -284,9 +290,6 @@ __device__ __forceinline__ void load_chunk(const int32_t* __restrict__ colidx, c
 // MAXB: deepest load batch (8 in the bandwidth kernels; 4 where register pressure matters more than the last few
 // percent on long segments -- the fallback walk of the short-row kernels).  The batch depth only re-times loads: the
 // accumulation order, hence the bits, do not depend on it.
-#ifndef H2GCN_MAIN_MAXB
-#define H2GCN_MAIN_MAXB 8
-#endif
 template <int VEC, int LPR, bool MASKED, bool OFF32, int MAXB = H2GCN_MAIN_MAXB, int NP>
 __device__ __forceinline__ void process_chunk(int c, float v, int n, int g, const GatherAddr<OFF32>& addr,
                                               bool lane_active, float (&acc)[NP][VEC]) {
@@ -489,6 +492,7 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? (FB == 4 && !SUM ? H2GCN_S
     __shared__ float partial[kWavesPerBlock][kMaxTileCols];
     using off_t = typename std::conditional<OFF32, uint32_t, int64_t>::type;
     constexpr int NP = Tree<LPR>::NP;
+    constexpr int kMainB = LPR >= 32 ? H2GCN_WIDE_MAXB : H2GCN_MAIN_MAXB;
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = wave_uniform(threadIdx.x >> 6);
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? (FB == 4 && !SUM ? H2GCN_S
                 const int64_t sb = h.rowptr[row], se = h.rowptr[row + 1];
                 const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin + (col0 - col_begin) - kBias),
                                              EXACT ? lane_off0 : (off_t)(li * VEC * 4), (off_t)(p.ld_src * 4)};
-                accumulate_segment<VEC, LPR, !EXACT, OFF32>(h.colidx, h.vals, sb, se, wave, kWavesPerBlock, addr, lane,
+                accumulate_segment<VEC, LPR, !EXACT, OFF32, kMainB>(h.colidx, h.vals, sb, se, wave, kWavesPerBlock, addr, lane,
                                                             lane_active, acc);
             }
             float tot[VEC];
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? (FB == 4 && !SUM ? H2GCN_S
                 const HopCsr& h = p.hop[s];
                 const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin + (col0 - col_begin) - kBias),
                                              EXACT ? lane_off0 : (off_t)(li * VEC * 4), (off_t)(p.ld_src * 4)};
-                accumulate_segment<VEC, LPR, !EXACT, OFF32>(h.colidx, h.vals, sb, se, 0, 1, addr, lane, lane_active, acc);
+                accumulate_segment<VEC, LPR, !EXACT, OFF32, kMainB>(h.colidx, h.vals, sb, se, 0, 1, addr, lane, lane_active, acc);
                 if constexpr (!SUM) {
                     float tot[VEC];
                     fold_tree<VEC, LPR, NP>(acc, tot);

@@ -182,9 +182,9 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
  *   launch wants (0 = the plain launch is already the fastest); NULL / too small simply selects the plain launch.
  *   The copy is a pure performance device, used (a) when the row stride of X is a multiple of 1 KiB (e.g. a contiguous
  *   [N, 256] embedding) and the operand is far beyond the caches: gathering column slices straight out of such rows
- *   wastes three quarters of the cache sets; (b) when the rows are wide and not cache-line aligned (ld*4 not a multiple
- *   of 128; forward d > 128, adjoint d > 256) on such an operand: the copy's 64-column blocks are aligned (zero-padded
- *   when d is not a multiple of 4).  Results are bit-identical with and without scratch (canonical summation tree).
+ *   wastes three quarters of the cache sets; (b) when the rows are wide and do not start on cache lines (base or ld*4 not
+ *   a multiple of 128; forward d > 128, adjoint d > 256) on such an operand: the copy's 64-column blocks are aligned
+ *   (zero-padded when d is not a multiple of 4).  Rows that DO start on cache lines are sliced 64 columns wide in place.  Results are bit-identical with and without scratch (canonical summation tree).
  *   The scratch is only used by this launch (on `stream`); launches that may run concurrently need separate scratch.
  * bias / H2GCN_LAUNCH_RELU: fused epilogue of the store, Y = act(A X + bias[c]) -- what SparseDense.call applies
  *   after its sparse product (reference h2gcn/models/_layers.py:45-52: `+ self.bias`, then `self.activation`), so
@@ -192,7 +192,7 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
  *
  * h2gcn_spmm_workspace_bytes: adjoint != 0 asks about h2gcn_spmm_hops_T_opts_f32; src_dev / ld_src / ld_src_hop
  *   describe the gather source of that launch (forward: X_dev, ldx, 0; adjoint: dY_dev, ldg_row, ldg_hop); the pointer
- *   and the hop stride are reserved (alignment no longer matters) and never dereferenced.
+ *   is only inspected (do its rows start on 128-byte cache lines?), never dereferenced.
  */
 #define H2GCN_LAUNCH_RELU 0x1u
 typedef struct h2gcn_launch_opts {

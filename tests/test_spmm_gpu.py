@@ -216,6 +216,8 @@ def test_scratch_copy_for_rows_that_are_not_line_aligned():
     xp = C.c_void_p(x.data_ptr())
     assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 0, xp, d, 0, d) == n * 4 * 64 * 4      # 4 blocks of 64 columns
     assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 0, xp, 224, 0, d) == 0                 # rows padded to 896 B: aligned
+    assert plan.schedule(d, ld_src=224)["slice_cols"] == 64 and not plan.schedule(d, ld_src=224)["scratch_copy"]   # sliced in place
+    assert L.h2gcn_spmm_workspace_bytes(plan._handle, 0, 0, C.c_void_p(x.data_ptr() + 16), 224, 0, d) == n * 4 * 64 * 4   # slot not on a line
     sched = plan.schedule(d)
     assert sched["scratch_copy"] and sched["slice_cols"] == 64 and sched["n_slices"] == 4
     ybuf = torch.full((n, 2, d + 8), 3.0, device=device)
@@ -224,6 +226,12 @@ def test_scratch_copy_for_rows_that_are_not_line_aligned():
     plan.use_workspace = False
     y_plain = plan.spmm(x)
     assert torch.equal(y_ws, y_plain)
+    # rows that DO start on cache lines (stride padded to 224 floats) are sliced 64 columns wide in place: same bits
+    xpad = torch.zeros((n, 224), device=device)
+    xpad[:, :d] = x
+    plan.use_workspace = True
+    assert torch.equal(plan.spmm(xpad[:, :d]), y_plain)
+    del xpad
     for r0 in (0, 4321, n - 8):
         parts = [synth.synth_hop_rows_np(degs[k], n, (15, 16)[k], r0, r0 + 8) for k in range(2)]
         cols = np.unique(np.concatenate([q[1] for q in parts]))

@@ -2,7 +2,7 @@
 # tools/sweep.sh <outfile> "<bench args>" ["<bench args>" ...] -- one condensed bench line per argument set (GPU box):
 # schedule, forward / adjoint kernel time and roofline fraction.  H2GCN_HIP_LIBRARY may point at an alternative build.
 #   tools/sweep.sh gpurun_out/s.txt "" "--d 100" "--shape arxiv --d 1433" "--shape lowdeg"
-OUT=$1; shift; : > "$OUT"
+OUT=$1; shift; mkdir -p "$(dirname "$OUT")"; : > "$OUT"
 for ARGS in "$@"; do
   echo "## $ARGS" >> "$OUT"
   timeout 900 python bench.py --no-cpu-baseline --no-probe --no-traffic --no-hbm-leg --steps 8 --warmup 2 $ARGS 2>>"$OUT.err" | tail -1 | python -c "
