@@ -251,12 +251,12 @@ class _FusedPropagation(torch.autograd.Function):
 
 
 def concat_buffer(n_rows: int, width: int, device) -> torch.Tensor:
-    """``[n_rows, width]`` fp32 view whose row stride is padded to a multiple of 32 floats: every row of the concat
-    buffer starts on a 128-byte cache line, so the gathers of a round touch ``ceil(slot_bytes / 128)`` lines per row
-    wherever the slot's offset allows (hidden sizes that are not multiples of 32, e.g. ``--hidden 100``; free: the
-    padding columns are never read or written)."""
-    ld = (width + 31) // 32 * 32
-    return torch.empty((n_rows, ld), dtype=torch.float32, device=device)[:, :width]
+    """The ``[n_rows, width]`` fp32 concat buffer, contiguous.  (Padding its row stride to a cache line was tried in round
+    3 and dropped: the hop launches gain < 2 % -- the slots inside a row still start off-line, so they take the
+    scratch-copy schedule either way -- while the stock dropout / classifier kernels that consume the buffer fall off
+    their vectorised paths on a non-contiguous view: +2.8 ms per products-scale step at ``--hidden 100``,
+    ``profiles/r03_train_step_hidden100.txt``.)"""
+    return torch.empty((n_rows, width), dtype=torch.float32, device=device)
 
 
 def fused_propagation(plan: HopPlan, r0: torch.Tensor, rounds: int) -> torch.Tensor:
