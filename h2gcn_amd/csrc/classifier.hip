@@ -1,0 +1,493 @@
+// classifier.hip -- the classifier side of an H2GCN training step as hand-written gfx950 kernels on the fp32 matrix cores:
+//
+//     Z = (X .* M / keep) @ W + b          (forward)          X: [N, K] concat buffer, K = 7 * hidden (448), W: [K, C], C <= 64
+//     dX = (G @ W^T) .* M / keep           (backward, data)   G: [N, C]
+//     dW = (X .* M / keep)^T @ G           (backward, weights)
+//
+// Reference: keras `Dropout(rate)` followed by the output `Dense` -- `D0.5-MO` of the network-setup DSL (reference
+// h2gcn/models/H2GCN.py:235-257 builds the two layers, :308-325 calls them in order; SURVEY.md 8(f) rank 2/3: "the final
+// dense classifier", "training loop on device").  With stock kernels this is five passes over the 4.3 GB buffer of the
+// products shape (dropout forward, skinny GEMM, two backward GEMMs, dropout backward: ~15 of a 68 ms step, the GEMMs at
+// 1.1-1.9 TB/s because C = 47 outputs starve a general GEMM tile).  Here every pass streams X (or writes dX) ONCE:
+//   * the dropout mask is a COUNTER-BASED function of (seed, step, row, column) -- two rounds of a 32-bit avalanche hash --
+//     recomputed wherever it is needed instead of stored or applied in a pass of its own;
+//   * the products run on v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain), C padded to 16-column tiles (47 -> 48),
+//     W staged through LDS in 128-row chunks whose layout makes the B-fragment reads 2-way (= full rate) bank accesses;
+//   * dW is accumulated per workgroup in registers over a contiguous row range and reduced in fixed order (deterministic).
+// HBM-bound by design: the MFMA time (0.66 ms at the f32 matrix peak for the products shape) hides under the stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <type_traits>
+
+#include "capi_internal.h"
+#include "h2gcn_hip.h"
+
+namespace {
+
+using h2gcn::fail;
+using f32x4 = float __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int kThreads = 256;   // 4 waves
+constexpr int kRowsPerWave = 32;
+constexpr int kRowsPerGroup = 4 * kRowsPerWave;
+#ifndef H2GCN_CLS_KC
+#define H2GCN_CLS_KC 64
+#endif
+constexpr int kKC = H2GCN_CLS_KC;   // rows of W per LDS chunk (forward) / output columns per chunk (dX): 64 keeps 5 waves per SIMD resident
+constexpr int kDwRowsPerStep = 4;
+
+__host__ __device__ constexpr int lds_stride(int nt) { return nt == 1 ? 16 : (nt <= 3 ? 48 : 80); }  // floats; stride % 32 == 16
+constexpr int kDxStride = kKC + 16;                                                                      // 80 (144 for 128-column chunks): % 32 == 16
+
+// ---- the mask generator (documented in include/h2gcn_hip.h; the test-side restatement reproduces it bit for bit) -------
+// One hash chain per aligned GROUP of four columns of a row (gid = row * ceil(K/4) + col/4, 64-bit) yields 64 bits, i.e. one
+// 16-bit field per element; an element is kept iff its field < keep_prob * 65536.  (The first version hashed every element
+// separately: 5 quarter-rate v_mul_lo_u32 per element made the VALU work exceed the MFMA work.)
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    return h ^ (h >> 16);
+}
+struct MaskKey {
+    uint32_t k0, k1, thr16;
+    int on;
+    int64_t groups_per_row;
+};
+__device__ __forceinline__ MaskKey make_key(uint64_t seed, const int64_t* step_dev, uint32_t thr16, int on, int K) {
+    const uint64_t step = (on && step_dev) ? (uint64_t)*step_dev : 0;
+    return MaskKey{(uint32_t)seed ^ ((uint32_t)step * 0x9E3779B9u), (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32), thr16, on, (int64_t)((K + 3) / 4)};
+}
+// the two hash words of the group holding (row, col): fields (w0 & 0xffff, w0 >> 16, w1 & 0xffff, w1 >> 16) for col % 4 = 0..3
+__device__ __forceinline__ void group_words(const MaskKey& m, int64_t row, int col, uint32_t& w0, uint32_t& w1) {
+    const uint64_t gid = (uint64_t)(row * m.groups_per_row + (col >> 2));
+    const uint32_t h1 = mix32((uint32_t)gid ^ m.k0);
+    w0 = mix32(h1 ^ ((uint32_t)(gid >> 32) * 0x9E3779B9u + m.k1));
+    w1 = mix32(w0 ^ 0x85EBCA6Bu);
+}
+__device__ __forceinline__ bool keep_field(const MaskKey& m, uint32_t w0, uint32_t w1, int j) {
+    const uint32_t w = (j & 2) ? w1 : w0;
+    return ((j & 1) ? (w >> 16) : (w & 0xFFFFu)) < m.thr16;
+}
+
+// ---- weight packing ------------------------------------------------------------------------------------------------------
+// forward image: row r of chunk c <-> k = 128 c + 16 g + 4 kq + j with r % 128 = (g*4 + j)*4 + kq: the four k's one
+// v_mfma_f32_16x16x4 step consumes (kq = lane >> 4) sit in adjacent LDS rows; [Kpad][stride], zero beyond K / C
+__global__ void pack_w_fwd_kernel(const float* __restrict__ w, int K, int C, int Kpad, int stride, float* __restrict__ out) {
+    const int total = Kpad * stride;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int r = t / stride, col = t - r * stride;
+        const int c = r / kKC, rr = r % kKC;
+        const int kq = rr & 3, j = (rr >> 2) & 3, g = rr >> 4;
+        const int k = c * kKC + 16 * g + 4 * kq + j;
+        out[t] = (k < K && col < C) ? w[(int64_t)k * C + col] : 0.f;
+    }
+}
+// backward-data image: chunk v of 128 output columns, row cc = 4 s + kq (the c index), column kk: W[128 v + kk][cc];
+// [n_chunks][Cpad][kDxStride], zero beyond K / C
+__global__ void pack_w_dx_kernel(const float* __restrict__ w, int K, int C, int Cpad, int n_chunks, float* __restrict__ out) {
+    const int total = n_chunks * Cpad * kDxStride;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int v = t / (Cpad * kDxStride), rem = t - v * (Cpad * kDxStride);
+        const int cc = rem / kDxStride, kk = rem - cc * kDxStride;
+        const int k = v * kKC + kk;
+        out[t] = (kk < kKC && k < K && cc < C) ? w[(int64_t)k * C + cc] : 0.f;
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// float4 of row `row` at columns k .. k+3 (k % 4 == 0; zero beyond the matrix).  Branch-light and with compile-time register
+// indices only: a runtime-indexed tail loop would send the caller's fragment array to scratch.
+__device__ __forceinline__ f4u load_row4(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int K, int64_t row, int k) {
+    f4u v = {0.f, 0.f, 0.f, 0.f};
+    if (row < n_rows && k < K) {
+        const float* p = X + row * ldx + k;
+        if (k + 4 <= K) {
+            v = *reinterpret_cast<const f4u*>(p);
+        } else {   // the last, partial group of a row whose width is not a multiple of 4
+            v[0] = p[0];
+            if (k + 1 < K) v[1] = p[1];
+            if (k + 2 < K) v[2] = p[2];
+        }
+    }
+    return v;
+}
+// dropout of the group (row, k .. k+3): kept elements scaled by 1 / keep_prob
+__device__ __forceinline__ f4u apply_mask(f4u v, const MaskKey& mk, int64_t row, int k, float inv_keep) {
+    if (mk.on) {
+        uint32_t w0, w1;
+        group_words(mk, row, k, w0, w1);
+        v[0] = (w0 & 0xFFFFu) < mk.thr16 ? v[0] * inv_keep : 0.f;
+        v[1] = (w0 >> 16) < mk.thr16 ? v[1] * inv_keep : 0.f;
+        v[2] = (w1 & 0xFFFFu) < mk.thr16 ? v[2] * inv_keep : 0.f;
+        v[3] = (w1 >> 16) < mk.thr16 ? v[3] * inv_keep : 0.f;
+    }
+    return v;
+}
+
+// ---- forward -------------------------------------------------------------------------------------------------------------
+// One workgroup = 4 waves x 32 rows; a wave owns 2 row tiles x NT column tiles of 16x16 accumulators.  W chunks of 128 rows
+// are double-buffered in LDS (one barrier per chunk).
+template <int NT>
+__global__ __launch_bounds__(kThreads) void dropout_dense_fwd_kernel(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int K,
+                                                                     const float* __restrict__ Wp, int Kpad, const float* __restrict__ bias,
+                                                                     int C, float inv_keep, uint32_t thr, int mask_on, uint64_t seed,
+                                                                     const int64_t* step_dev, float* __restrict__ Y, int64_t ldy) {
+    constexpr int S = lds_stride(NT);
+    extern __shared__ float lds[];   // 2 x kKC x S
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const MaskKey mk = make_key(seed, step_dev, thr, mask_on, K);
+    const int n_chunks = Kpad / kKC;
+    const int64_t n_groups = (n_rows + kRowsPerGroup - 1) / kRowsPerGroup;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t row_base = grp * kRowsPerGroup + (int64_t)wave * kRowsPerWave;
+        f32x4 acc[2][NT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < n_chunks; ++c) {
+            float* buf = lds + (c & 1) * (kKC * S);
+            // the wave's own X fragments first: their latency runs under the LDS fill and the barrier
+            f4u a[2][kKC / 16];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < kKC / 16; ++g) a[t][g] = load_row4(X, ldx, n_rows, K, row_base + 16 * t + i, c * kKC + 16 * g + 4 * kq);
+            // this buffer was last read two chunks ago; every wave has passed the barrier of the previous chunk since
+            {
+                const f32x4* src = reinterpret_cast<const f32x4*>(Wp + (int64_t)c * kKC * S);
+                f32x4* dst = reinterpret_cast<f32x4*>(buf);
+                for (int t = threadIdx.x; t < kKC * S / 4; t += kThreads) dst[t] = src[t];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < kKC / 16; ++g) {
+                const f4u a0 = apply_mask(a[0][g], mk, row_base + i, c * kKC + 16 * g + 4 * kq, inv_keep);
+                const f4u a1 = apply_mask(a[1][g], mk, row_base + 16 + i, c * kKC + 16 * g + 4 * kq, inv_keep);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* brow = buf + ((g * 4 + j) * 4 + kq) * S + i;
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) {
+                        const float b = brow[16 * u];
+                        acc[0][u] = mfma16(a0[j], b, acc[0][u]);
+                        acc[1][u] = mfma16(a1[j], b, acc[1][u]);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the next group's first fill must not overtake this group's last reads of buffer 0
+        // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int col = 16 * u + i;
+                if (col >= C) continue;
+                const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row_base + 16 * t + 4 * kq + r;
+                    if (row < n_rows) Y[row * ldy + col] = acc[t][u][r] + bv;
+                }
+            }
+    }
+}
+
+// ---- backward, data: dX = (G W^T) .* M / keep ---------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(kThreads) void dropout_dense_dx_kernel(const float* __restrict__ G, int64_t ldg, int64_t n_rows, int K, int C,
+                                                                    const float* __restrict__ Wtp, int n_chunks, float inv_keep,
+                                                                    uint32_t thr, int mask_on, uint64_t seed, const int64_t* step_dev,
+                                                                    float* __restrict__ dX, int64_t lddx) {
+    constexpr int CP = NT * 16, NS = NT * 4;
+    extern __shared__ float lds[];   // 2 x CP x kDxStride
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const MaskKey mk = make_key(seed, step_dev, thr, mask_on, K);
+    const int64_t n_groups = (n_rows + kRowsPerGroup - 1) / kRowsPerGroup;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t row_base = grp * kRowsPerGroup + (int64_t)wave * kRowsPerWave;
+        float ga[2][NS];   // A fragments: G[row_base + 16 t + i][4 s + kq]
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int64_t row = row_base + 16 * t + i;
+                const int cc = 4 * s + kq;
+                ga[t][s] = (row < n_rows && cc < C) ? G[row * ldg + cc] : 0.f;
+            }
+        for (int v = 0; v < n_chunks; ++v) {
+            float* buf = lds + (v & 1) * (CP * kDxStride);
+            {
+                const f32x4* src = reinterpret_cast<const f32x4*>(Wtp + (int64_t)v * CP * kDxStride);
+                f32x4* dst = reinterpret_cast<f32x4*>(buf);
+                for (int t = threadIdx.x; t < CP * kDxStride / 4; t += kThreads) dst[t] = src[t];
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int vv = 0; vv < kKC / 16; ++vv) {
+                const int c0 = v * kKC + 16 * vv;
+                if (c0 >= K) break;   // wave-uniform: tiles beyond the matrix
+                // TRANSPOSED tile: D = W-fragment (16 output columns x 4 c) * G^T (4 c x 16 rows), so that a lane ends up with
+                // FOUR CONSECUTIVE COLUMNS of one row (D[ii = 4 kq + r][n = i]): one 16-byte store and exactly one mask group
+                // per lane and row tile -- no cross-lane traffic, a quarter of the store instructions
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const float wf = buf[(4 * s + kq) * kDxStride + 16 * vv + i];   // A[ii = i][kk = kq] = W[c0 + i][4 s + kq]
+                    acc0 = mfma16(wf, ga[0][s], acc0);                              // B[kk = kq][n = i] = G[row][4 s + kq]
+                    acc1 = mfma16(wf, ga[1][s], acc1);
+                }
+                const int col = c0 + 4 * kq;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int64_t row = row_base + 16 * t + i;
+                    if (row >= n_rows || col >= K) continue;
+                    f4u o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = t == 0 ? acc0[r] : acc1[r];
+                    if (mk.on) o = apply_mask(o, mk, row, col, inv_keep);
+                    float* dst = dX + row * lddx + col;
+                    if (col + 4 <= K) {
+                        __builtin_nontemporal_store(o, reinterpret_cast<f4u*>(dst));
+                    } else {
+                        dst[0] = o[0];
+                        if (col + 1 < K) dst[1] = o[1];
+                        if (col + 2 < K) dst[2] = o[2];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- backward, weights: dW = (X .* M / keep)^T G, per-workgroup partials ------------------------------------------------------
+// grid.y = blocks of 512 columns of X (8 segments of 64); wave w of a workgroup owns segments w and w + 4.  M index of a tile
+// (segment, j): ii <-> k = 64 seg + 4 ii + j.  The reduction runs over the workgroup's row range in steps of 4 rows.
+template <int NT>
+__global__ __launch_bounds__(kThreads) void dropout_dense_dw_kernel(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int K,
+                                                                    const float* __restrict__ G, int64_t ldg, int C, float inv_keep,
+                                                                    uint32_t thr, int mask_on, uint64_t seed, const int64_t* step_dev,
+                                                                    int64_t rows_per_wg, float* __restrict__ partial, int Kp) {
+    constexpr int CP = NT * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const MaskKey mk = make_key(seed, step_dev, thr, mask_on, K);
+    const int seg0 = blockIdx.y * 8 + wave;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_wg, r_end = min(r_begin + rows_per_wg, n_rows);
+    f32x4 acc[2][4][NT];
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[w2][j][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // software pipeline: the operands of step s+1 are requested before the 8 * NT MFMAs of step s are issued
+    auto fetch = [&](int64_t r0, f4u (&xa)[2], float (&gb)[NT]) {
+        const int64_t row = r0 + kq;
+        const bool row_ok = row < r_end;
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) xa[w2] = load_row4(X, ldx, row_ok ? n_rows : 0, K, row, 64 * (seg0 + 4 * w2) + 4 * i);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) gb[u] = (row_ok && 16 * u + i < C) ? G[row * ldg + 16 * u + i] : 0.f;
+    };
+    f4u xa_n[2];
+    float gb_n[NT];
+    if (r_begin < r_end) fetch(r_begin, xa_n, gb_n);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += kDwRowsPerStep) {
+        f4u xa[2] = {xa_n[0], xa_n[1]};
+        float gb[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) gb[u] = gb_n[u];
+        if (r0 + kDwRowsPerStep < r_end) fetch(r0 + kDwRowsPerStep, xa_n, gb_n);
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+            const f4u xm = apply_mask(xa[w2], mk, r0 + kq, 64 * (seg0 + 4 * w2) + 4 * i, inv_keep);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[w2][j][u] = mfma16(xm[j], gb[u], acc[w2][j][u]);
+        }
+    }
+    float* out = partial + (int64_t)blockIdx.x * Kp * CP;
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 64 * (seg0 + 4 * w2) + 4 * (4 * kq + r) + j;
+                    if (k < Kp) out[(int64_t)k * CP + 16 * u + i] = acc[w2][j][u][r];
+                }
+}
+
+// dW[k][c] = sum over workgroups, in order (deterministic)
+__global__ void reduce_dw_kernel(const float* __restrict__ partial, int n_parts, int Kp, int CP, int K, int C, float* __restrict__ dW) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < K * C; t += gridDim.x * blockDim.x) {
+        const int k = t / C, c = t - k * C;
+        float s = 0.f;
+        for (int p = 0; p < n_parts; ++p) s += partial[((int64_t)p * Kp + k) * CP + c];
+        dW[t] = s;
+    }
+}
+
+struct Shape {
+    int nt, kpad, cp, n_chunks, kp, gy;
+    int64_t gx, rows_per_wg;
+    size_t off_wfwd, off_wdx, off_partial, total;
+};
+
+int cu_count() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+}
+
+Shape shape_of(int64_t n_rows, int K, int C) {
+    Shape s;
+    s.nt = (C + 15) / 16;
+    s.cp = s.nt * 16;
+    s.kpad = (K + kKC - 1) / kKC * kKC;
+    s.n_chunks = s.kpad / kKC;
+    s.gy = (K + 511) / 512;
+    s.kp = s.gy * 512;
+    // dW: enough workgroups to fill the chip, each over a contiguous row range that is a multiple of 4 rows
+    const int64_t want = std::max<int64_t>(1, (int64_t)cu_count() * 2 / s.gy);
+    int64_t per = (n_rows + want - 1) / want;
+    per = std::max<int64_t>(64, (per + 3) / 4 * 4);
+    s.rows_per_wg = per;
+    s.gx = std::max<int64_t>(1, (n_rows + per - 1) / per);
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    s.off_wfwd = 0;
+    s.off_wdx = al((size_t)s.kpad * lds_stride(s.nt) * 4);
+    s.off_partial = s.off_wdx + al((size_t)s.n_chunks * s.cp * kDxStride * 4);
+    s.total = s.off_partial + al((size_t)s.gx * s.kp * s.cp * 4);
+    return s;
+}
+
+uint32_t keep_threshold(float keep_prob) {   // 16-bit fields: kept iff field < keep_prob * 65536
+    const double t = (double)keep_prob * 65536.0;
+    return t >= 65536.0 ? 65536u : (uint32_t)t;
+}
+
+int check_common(const void* X, int64_t ld, int64_t n_rows, int K, const void* W, int C, float keep_prob) {
+    if (n_rows < 0 || K < 1 || C < 1 || C > 64) return fail(H2GCN_ERR_INVALID_ARGUMENT, "dropout_dense: n_rows %lld, K %d, C %d (C <= 64)", (long long)n_rows, K, C);
+    if (ld < K) return fail(H2GCN_ERR_INVALID_ARGUMENT, "dropout_dense: row stride %lld < K = %d", (long long)ld, K);
+    if ((!X && n_rows > 0) || !W) return fail(H2GCN_ERR_INVALID_ARGUMENT, "dropout_dense: NULL operand");
+    if (!(keep_prob > 0.f) || keep_prob > 1.f) return fail(H2GCN_ERR_INVALID_ARGUMENT, "dropout_dense: keep_prob = %g outside (0, 1]", (double)keep_prob);
+    return H2GCN_OK;
+}
+
+template <typename F>
+int with_nt(int nt, F&& f) {
+    switch (nt) {
+        case 1: return f(std::integral_constant<int, 1>());
+        case 2: return f(std::integral_constant<int, 2>());
+        case 3: return f(std::integral_constant<int, 3>());
+        default: return f(std::integral_constant<int, 4>());
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t h2gcn_dropout_dense_workspace_bytes(int64_t n_rows, int32_t k, int32_t c) {
+    if (n_rows < 0 || k < 1 || c < 1 || c > 64) return 0;
+    return shape_of(n_rows, k, c).total;
+}
+
+int h2gcn_dropout_dense_f32(const float* X, int64_t ldx, int64_t n_rows, int32_t K, const float* W, int32_t C, const float* bias,
+                            float keep_prob, uint64_t seed, const int64_t* step_dev, float* Y, int64_t ldy, void* workspace,
+                            size_t workspace_bytes, void* stream_v) {
+    int st = check_common(X, ldx, n_rows, K, W, C, keep_prob);
+    if (st != H2GCN_OK) return st;
+    if (n_rows == 0) return H2GCN_OK;
+    if (!Y || ldy < C) return fail(H2GCN_ERR_INVALID_ARGUMENT, "dropout_dense: bad output (ldy %lld)", (long long)ldy);
+    const Shape s = shape_of(n_rows, K, C);
+    if (!workspace || workspace_bytes < s.total || ((uintptr_t)workspace & 15u))
+        return fail(H2GCN_ERR_INVALID_ARGUMENT, "dropout_dense: workspace of %zu bytes (16-byte aligned) needed, got %zu", s.total, workspace_bytes);
+    hipStream_t stream = (hipStream_t)stream_v;
+    float* wp = (float*)((char*)workspace + s.off_wfwd);
+    const int S = lds_stride(s.nt);
+    hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(64), dim3(256), 0, stream, W, (int)K, (int)C, s.kpad, S, wp);
+    H2GCN_HIP_TRY(hipGetLastError());
+    const int mask_on = keep_prob < 1.f ? 1 : 0;
+    const size_t lds_bytes = (size_t)2 * kKC * S * 4;
+    const int64_t n_groups = (n_rows + kRowsPerGroup - 1) / kRowsPerGroup;
+    const unsigned grid = (unsigned)std::min<int64_t>(n_groups, (int64_t)cu_count() * 6);
+    return with_nt(s.nt, [&](auto nt_c) -> int {
+        constexpr int NT = decltype(nt_c)::value;
+        H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)dropout_dense_fwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((dropout_dense_fwd_kernel<NT>), dim3(grid), dim3(kThreads), lds_bytes, stream, X, ldx, n_rows, (int)K, (const float*)wp,
+                           s.kpad, bias, (int)C, 1.f / keep_prob, keep_threshold(keep_prob), mask_on, seed, step_dev, Y, ldy);
+        H2GCN_HIP_TRY(hipGetLastError());
+        return H2GCN_OK;
+    });
+}
+
+int h2gcn_dropout_dense_backward_f32(const float* X, int64_t ldx, int64_t n_rows, int32_t K, const float* W, int32_t C, const float* G,
+                                     int64_t ldg, float keep_prob, uint64_t seed, const int64_t* step_dev, float* dX, int64_t lddx,
+                                     float* dW, void* workspace, size_t workspace_bytes, void* stream_v) {
+    int st = check_common(X, ldx, n_rows, K, W, C, keep_prob);
+    if (st != H2GCN_OK) return st;
+    if (!G && n_rows > 0) return fail(H2GCN_ERR_INVALID_ARGUMENT, "dropout_dense_backward: G is NULL");
+    if (ldg < C || (dX && lddx < K)) return fail(H2GCN_ERR_INVALID_ARGUMENT, "dropout_dense_backward: bad strides");
+    const Shape s = shape_of(n_rows, K, C);
+    if (!workspace || workspace_bytes < s.total || ((uintptr_t)workspace & 15u))
+        return fail(H2GCN_ERR_INVALID_ARGUMENT, "dropout_dense_backward: workspace of %zu bytes (16-byte aligned) needed, got %zu", s.total, workspace_bytes);
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int mask_on = keep_prob < 1.f ? 1 : 0;
+    const float inv_keep = 1.f / keep_prob;
+    const uint32_t thr = keep_threshold(keep_prob);
+    if (n_rows == 0) {
+        if (dW) H2GCN_HIP_TRY(hipMemsetAsync(dW, 0, (size_t)K * C * 4, stream));
+        return H2GCN_OK;
+    }
+    if (dX) {
+        float* wtp = (float*)((char*)workspace + s.off_wdx);
+        hipLaunchKernelGGL(pack_w_dx_kernel, dim3(64), dim3(256), 0, stream, W, (int)K, (int)C, s.cp, s.n_chunks, wtp);
+        H2GCN_HIP_TRY(hipGetLastError());
+        const size_t lds_bytes = (size_t)2 * s.cp * kDxStride * 4;
+        const int64_t n_groups = (n_rows + kRowsPerGroup - 1) / kRowsPerGroup;
+        const unsigned grid = (unsigned)std::min<int64_t>(n_groups, (int64_t)cu_count() * 6);
+        st = with_nt(s.nt, [&](auto nt_c) -> int {
+            constexpr int NT = decltype(nt_c)::value;
+            H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)dropout_dense_dx_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL((dropout_dense_dx_kernel<NT>), dim3(grid), dim3(kThreads), lds_bytes, stream, G, ldg, n_rows, (int)K, (int)C,
+                               (const float*)wtp, s.n_chunks, inv_keep, thr, mask_on, seed, step_dev, dX, lddx);
+            H2GCN_HIP_TRY(hipGetLastError());
+            return H2GCN_OK;
+        });
+        if (st != H2GCN_OK) return st;
+    }
+    if (dW) {
+        float* part = (float*)((char*)workspace + s.off_partial);
+        st = with_nt(s.nt, [&](auto nt_c) -> int {
+            constexpr int NT = decltype(nt_c)::value;
+            hipLaunchKernelGGL((dropout_dense_dw_kernel<NT>), dim3((unsigned)s.gx, (unsigned)s.gy), dim3(kThreads), 0, stream, X, ldx, n_rows, (int)K,
+                               G, ldg, (int)C, inv_keep, thr, mask_on, seed, step_dev, s.rows_per_wg, part, s.kp);
+            H2GCN_HIP_TRY(hipGetLastError());
+            return H2GCN_OK;
+        });
+        if (st != H2GCN_OK) return st;
+        hipLaunchKernelGGL(reduce_dw_kernel, dim3((unsigned)std::min(256, (K * C + 255) / 256)), dim3(256), 0, stream, (const float*)part, (int)s.gx,
+                           s.kp, s.cp, (int)K, (int)C, dW);
+        H2GCN_HIP_TRY(hipGetLastError());
+    }
+    return H2GCN_OK;
+}
+
+}  // extern "C"

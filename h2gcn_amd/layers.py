@@ -272,3 +272,102 @@ def fused_propagation(plan: HopPlan, r0: torch.Tensor, rounds: int) -> torch.Ten
 
 class _NoCtx:
     pass
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Dropout + output Dense in one pass over the concat buffer (csrc/classifier.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+def _dd_workspace(n: int, k: int, c: int, device) -> torch.Tensor:
+    from . import _capi
+    nbytes = int(_capi.lib().h2gcn_dropout_dense_workspace_bytes(n, k, c))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+class _DropoutDenseFn(torch.autograd.Function):
+    """``Z = (X .* M / keep) @ W + b`` and its gradients on the library's fp32-MFMA kernels; the mask ``M`` is a counter-based
+    function of (seed, step, row, column), recomputed in the backward kernels instead of being stored."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias, keep_prob, seed, step_dev):
+        import ctypes as C
+
+        from . import _capi
+        n, k = x.shape
+        c = kernel.shape[1]
+        w = kernel.contiguous()
+        z = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        ws = _dd_workspace(n, k, c, x.device)
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _capi.check(_capi.lib().h2gcn_dropout_dense_f32(
+                C.c_void_p(x.data_ptr()), x.stride(0), n, k, C.c_void_p(w.data_ptr()), c,
+                C.c_void_p(bias.data_ptr()) if bias is not None else None, float(keep_prob), int(seed),
+                C.c_void_p(step_dev.data_ptr()) if step_dev is not None else None, C.c_void_p(z.data_ptr()), z.stride(0),
+                C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream)))
+        ctx.save_for_backward(x, w, step_dev if step_dev is not None else torch.empty(0, device=x.device))
+        ctx.keep_prob, ctx.seed, ctx.has_bias, ctx.has_step = float(keep_prob), int(seed), bias is not None, step_dev is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+
+        from . import _capi
+        x, w, step = ctx.saved_tensors
+        n, k = x.shape
+        c = w.shape[1]
+        g = g.contiguous()
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = torch.empty((n, k), dtype=torch.float32, device=x.device) if need_dx else None
+        dw = torch.empty((k, c), dtype=torch.float32, device=x.device) if need_dw else None
+        if need_dx or need_dw:
+            ws = _dd_workspace(n, k, c, x.device)
+            with torch.cuda.device(x.device):
+                stream = torch.cuda.current_stream(x.device).cuda_stream
+                _capi.check(_capi.lib().h2gcn_dropout_dense_backward_f32(
+                    C.c_void_p(x.data_ptr()), x.stride(0), n, k, C.c_void_p(w.data_ptr()), c, C.c_void_p(g.data_ptr()), g.stride(0),
+                    ctx.keep_prob, ctx.seed, C.c_void_p(step.data_ptr()) if ctx.has_step else None,
+                    C.c_void_p(dx.data_ptr()) if need_dx else None, dx.stride(0) if need_dx else k,
+                    C.c_void_p(dw.data_ptr()) if need_dw else None, C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream)))
+        db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None, None
+
+
+class DropoutDense(torch.nn.Module):
+    """keras ``Dropout(rate)`` followed by ``Dense(units)`` -- the ``D0.5-MO`` tail of the network setup (reference
+    ``h2gcn/models/H2GCN.py:235-257``, called in order at ``:308-325``) -- as ONE pass over the ``[N, K]`` input per
+    direction: the dropout mask is drawn from a counter-based generator inside the fp32-MFMA product kernels of
+    ``csrc/classifier.hip`` (forward, ``dX``, ``dW``) instead of being materialised by a pass of its own.  Same parameters
+    as the unfused pair (``kernel [K, units]``, optional ``bias``); in evaluation the mask is off and the layer is the plain
+    product.  Inputs the kernels do not cover (CPU tensors, ``units > 64``, non-fp32) take the stock two-op path.
+
+    The mask stream differs from torch's (and from TensorFlow's, which nothing can reproduce): one mask per training
+    forward, keyed by ``(seed, step)``; ``step`` lives in a device counter bumped by a stream-ordered op, so a replayed
+    hipGraph draws a fresh mask every epoch."""
+
+    def __init__(self, input_dim: int, units: int, use_bias: bool, drop_prob: float, seed: Optional[int] = None):
+        super().__init__()
+        self.kernel = torch.nn.Parameter(torch.empty(input_dim, units))
+        torch.nn.init.xavier_uniform_(self.kernel)
+        self.bias = torch.nn.Parameter(torch.zeros(units)) if use_bias else None
+        self.drop_prob = float(drop_prob)
+        self.seed = int(torch.initial_seed() if seed is None else seed) & 0x7FFFFFFFFFFFFFFF
+        self.register_buffer("_step", torch.zeros(1, dtype=torch.int64), persistent=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        training = self.training and self.drop_prob > 0.0
+        fused_ok = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.kernel.shape[1] <= 64
+                    and (x.shape[1] <= 1 or x.stride(1) == 1) and x.stride(0) >= x.shape[1])
+        if not fused_ok:
+            if training:
+                x = torch.nn.functional.dropout(x, self.drop_prob, True)
+            y = x @ self.kernel
+            return y if self.bias is None else y + self.bias
+        step = None
+        if training:
+            self._step += 1                      # stream-ordered: a captured graph bumps it on every replay
+            step = self._step.clone()            # the value this forward (and its backward) uses
+        return _DropoutDenseFn.apply(x, self.kernel, self.bias, 1.0 - self.drop_prob if training else 1.0, self.seed, step)
+
+    def extra_repr(self) -> str:
+        return f"in={self.kernel.shape[0]}, units={self.kernel.shape[1]}, bias={self.bias is not None}, drop={self.drop_prob}"

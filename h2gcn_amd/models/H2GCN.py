@@ -38,6 +38,9 @@ def add_subparser_args(parser):
     g.add_argument("--no_feature_normalize", action="store_true")
     g.add_argument("--adj_norm", choices=["sym", "rw"], default="sym",
                    help="hop normalisation: sym = D^-1/2 A D^-1/2 (reference default), rw = D^-1 A")
+    g.add_argument("--no_fused_classifier", action="store_true",
+                   help="run `D<rate>` followed by a dense layer as the stock dropout + matmul pair instead of the library's "
+                        "one-pass dropout+Dense kernels (csrc/classifier.hip)")
     g.add_argument("--sparse_dropout_at_eval", action="store_true",
                    help="reproduce the reference's SparseDropout, which Keras never switches off (it drops sparse feature "
                         "values during evaluation as well); default: inactive in evaluation like every other dropout")
@@ -93,7 +96,8 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
     model = H2GCN(layer_setups, input_dim=(feats.shape[1] if dense_features else feats.n_cols),
                   n_hops=(tensors["adj_hops"].n_hops if tensors["adj_hops"] is not None else 0),
                   sparse_input=not dense_features, l2_regularize_weight=l2_regularize_weight,
-                  sparse_dropout_at_eval=getattr(args, "sparse_dropout_at_eval", False)).to(device)
+                  sparse_dropout_at_eval=getattr(args, "sparse_dropout_at_eval", False),
+                  fused_classifier=not getattr(args, "no_fused_classifier", False)).to(device)
     sharded = _is_sharded()
     if sharded:  # replicas must start identical whatever the seeding on each rank (e.g. --random_seed 0)
         for p_ in model.parameters():
@@ -423,7 +427,7 @@ class H2GCN(torch.nn.Module):
     concats (``:339-341``).  Feature widths are tracked statically (keras builds lazily)."""
 
     def __init__(self, layer_setups, input_dim: int, n_hops: int = 2, sparse_input: bool = True,
-                 l2_regularize_weight: float = 0.0, sparse_dropout_at_eval: bool = False):
+                 l2_regularize_weight: float = 0.0, sparse_dropout_at_eval: bool = False, fused_classifier: bool = True):
         super().__init__()
         self.l2 = float(l2_regularize_weight)
         self.layer_objs = torch.nn.ModuleList()
@@ -437,6 +441,7 @@ class H2GCN(torch.nn.Module):
         pending_hops = None          # set after a G layer until the next V: activation is [N, H, width]
         setups = list(layer_setups)
         fuse_relu_into = None        # index of a SparseDense whose following R layer became its store epilogue
+        pending_dropout = None       # rate of a dense-input D layer that the next dense layer absorbs (DropoutDense)
         for pos, (kind, conf) in enumerate(setups):
             conf = dict(conf)
             tag = conf.pop("tag", None)
@@ -454,13 +459,23 @@ class H2GCN(torch.nn.Module):
                     layer = L.SparseDense(width, conf["units"], use_bias=conf["use_bias"], activation="relu" if fuse else None)
                     fuse_relu_into = ind if fuse else None
                     sparse_input = False
+                elif pending_dropout is not None:
+                    # `D0.5-MO`: dropout + dense in one pass over the concat buffer (mask drawn inside the product kernels)
+                    layer = L.DropoutDense(width, conf["units"], conf["use_bias"], pending_dropout)
+                    pending_dropout = None
                 else:
                     layer = Dense(width, conf["units"], conf["use_bias"])
                 self.regularized.append(layer)
                 width = conf["units"]
             elif kind == Layer.DROPOUT:
-                layer = (L.SparseDropout(conf["dropout_rate"], at_eval=sparse_dropout_at_eval) if sparse_input
-                         else torch.nn.Dropout(conf["dropout_rate"]))
+                nxt_kind, nxt_conf = setups[pos + 1] if pos + 1 < len(setups) else (None, {})
+                if (fused_classifier and not sparse_input and tag is None and nxt_kind == Layer.DENSE and nxt_conf["units"] <= 64
+                        and pending_hops is None):
+                    pending_dropout = conf["dropout_rate"]
+                    layer = torch.nn.Identity()   # the following dense layer applies the dropout itself
+                else:
+                    layer = (L.SparseDropout(conf["dropout_rate"], at_eval=sparse_dropout_at_eval) if sparse_input
+                             else torch.nn.Dropout(conf["dropout_rate"]))
             elif kind == Layer.SLICE:
                 self.concat_inds.add(ind)
                 layer = L.SliceLayer(**conf)

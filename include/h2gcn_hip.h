@@ -296,6 +296,44 @@ int h2gcn_hop_normalize_rows(int64_t n_rows, const int64_t* rowptr_dev, const in
                              float* vals_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * The classifier side of a training step: keras `Dropout(rate)` followed by the output `Dense` -- `D0.5-MO` of the
+ * network-setup DSL (reference h2gcn/models/H2GCN.py:235-257 builds the two layers, :308-325 calls them in order) -- as
+ * ONE pass over the [N, K] concat buffer per direction, on the fp32 matrix cores (h2gcn_amd/csrc/classifier.hip):
+ *
+ *     forward    Z[n, c]  = sum_k D[n, k] * W[k, c] + bias[c]          D[n, k] = keep(n, k) ? X[n, k] / keep_prob : 0
+ *     backward   dX[n, k] = keep(n, k) ? (sum_c G[n, c] * W[k, c]) / keep_prob : 0
+ *                dW[k, c] = sum_n D[n, k] * G[n, c]                     (db = column sums of G: left to the caller)
+ *
+ * The dropout mask is COUNTER-BASED, recomputed wherever it is needed instead of stored.  One hash chain per aligned group
+ * of four columns of a row yields four 16-bit fields:
+ *     gid = n * ceil(K / 4) + k / 4  (64-bit),   keep(n, k)  <=>  field[k % 4] < keep_prob * 65536,
+ *     w0 = mix(mix(lo32(gid) ^ key0) ^ (hi32(gid) * 0x9E3779B9 + key1)),   w1 = mix(w0 ^ 0x85EBCA6B),
+ *     field = (w0 & 0xffff, w0 >> 16, w1 & 0xffff, w1 >> 16),
+ *     key0 = lo32(seed) ^ (lo32(step) * 0x9E3779B9),  key1 = hi32(seed) ^ hi32(step),
+ *     mix(h): h ^= h >> 16; h *= 0x7FEB352D; h ^= h >> 15; h *= 0x846CA68B; h ^= h >> 16   (mod 2^32)
+ * `step` is read from DEVICE memory (*step_dev; NULL = 0) so that a captured hipGraph draws a fresh mask on every replay
+ * (the caller bumps the counter with a stream-ordered op); the backward call must see the value its forward saw.
+ * keep_prob = 1 switches the mask off (evaluation).  TensorFlow's stateful RNG stream cannot be reproduced by any other
+ * implementation, so parity with the reference is statistical here (keep rate) and exact for everything that is a
+ * function of the mask (oracle/classifier.py restates the generator bit for bit).
+ *
+ *   X        fp32 [n_rows, K], row stride ldx (any 4-byte aligned base / stride)      W   fp32 [K, C] contiguous, C <= 64
+ *   G        fp32 [n_rows, C], row stride ldg                                         dX  fp32 [n_rows, K], row stride lddx, or NULL
+ *   dW       fp32 [K, C] contiguous (overwritten), or NULL; partial sums are added in a fixed order (deterministic)
+ *   workspace  h2gcn_dropout_dense_workspace_bytes(n_rows, K, C) bytes, 16-byte aligned, used by this call on `stream`
+ * Arithmetic: v_mfma_f32_16x16x4_f32, i.e. exact fp32 multiply-adds (no reduced precision); the summation order over k
+ * (forward), c (dX) and rows (dW) is fixed by the shapes.
+ */
+size_t h2gcn_dropout_dense_workspace_bytes(int64_t n_rows, int32_t k, int32_t c);
+int h2gcn_dropout_dense_f32(const float* X_dev, int64_t ldx, int64_t n_rows, int32_t k, const float* W_dev, int32_t c,
+                            const float* bias_dev, float keep_prob, uint64_t seed, const int64_t* step_dev,
+                            float* Z_dev, int64_t ldz, void* workspace_dev, size_t workspace_bytes, void* stream);
+int h2gcn_dropout_dense_backward_f32(const float* X_dev, int64_t ldx, int64_t n_rows, int32_t k, const float* W_dev, int32_t c,
+                                     const float* G_dev, int64_t ldg, float keep_prob, uint64_t seed, const int64_t* step_dev,
+                                     float* dX_dev, int64_t lddx, float* dW_dev, void* workspace_dev, size_t workspace_bytes,
+                                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Row-shard exchange between the GPUs of one node (no counterpart in the reference: it is single-process,
  * single-device -- SURVEY.md 8(e) adds the row partition).  Before a hop aggregation every rank needs the whole
  * embedding X[N, d] while it owns only X[rows_p, :]; this object performs that all-gather WITHOUT a collective

@@ -8,7 +8,7 @@ from h2gcn_amd import HopPlan, synth
 from h2gcn_amd.models import parse_network_setup
 from h2gcn_amd.models.H2GCN import H2GCN, make_optimizer
 cfg = synth.SHAPES["products"]; n = cfg["n"]; F, C = 100, 47
-HIDDEN = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+HIDDEN = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64
 dev = torch.device("cuda:0")
 degs = [synth.synth_degrees(n, cfg["nnz_per_hop"], s, n) for s in (123, 124)]
 csr = [synth.synth_hop_rows(degs[k], n, (123, 124)[k], 0, n, dev) for k in range(2)]
@@ -19,7 +19,7 @@ feats = synth.synth_features(F, 5, 0, n, dev)
 labels = torch.nn.functional.one_hot(torch.randint(0, C, (n,), device=dev), C).float()
 mask = torch.rand(n, device=dev) < 0.1
 model = H2GCN(parse_network_setup(f"M{HIDDEN}-R-T1-G-V-T2-G-V-C1-C2-D0.5-MO", C), input_dim=F, n_hops=2, sparse_input=False,
-              l2_regularize_weight=5e-4).to(dev)
+              l2_regularize_weight=5e-4, fused_classifier="--stock-classifier" not in sys.argv).to(dev)
 opt = make_optimizer("adam", model.parameters(), 0.01)
 def step():
     model.train(); opt.zero_grad(set_to_none=True)
