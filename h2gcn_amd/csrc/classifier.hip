@@ -272,19 +272,24 @@ __global__ __launch_bounds__(kThreads) void dropout_dense_dx_kernel(const float*
 }
 
 // ---- backward, weights: dW = (X .* M / keep)^T G, per-workgroup partials ------------------------------------------------------
-// grid.y = blocks of 512 columns of X (8 segments of 64); wave w of a workgroup owns segments w and w + 4.  M index of a tile
-// (segment, j): ii <-> k = 64 seg + 4 ii + j.  The reduction runs over the workgroup's row range in steps of 4 rows.
+// grid.y = blocks of 512 columns of X (8 segments of 64); a wave owns one PAIR of adjacent segments.  Narrow inputs (K <= 256:
+// fewer than four pairs) split the workgroup's rows over the otherwise idle waves instead (row_split = 2 or 4 sub-ranges,
+// each with its own partial result).  M index of a tile (segment, j): ii <-> k = 64 seg + 4 ii + j.  The reduction runs over
+// the row range in steps of 4 rows.
 template <int NT>
 __global__ __launch_bounds__(kThreads) void dropout_dense_dw_kernel(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int K,
                                                                     const float* __restrict__ G, int64_t ldg, int C, float inv_keep,
                                                                     uint32_t thr, int mask_on, uint64_t seed, const int64_t* step_dev,
-                                                                    int64_t rows_per_wg, float* __restrict__ partial, int Kp) {
+                                                                    int64_t rows_per_wg, float* __restrict__ partial, int Kp, int row_split) {
     constexpr int CP = NT * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const MaskKey mk = make_key(seed, step_dev, thr, mask_on, K);
-    const int seg0 = blockIdx.y * 8 + wave;
-    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_wg, r_end = min(r_begin + rows_per_wg, n_rows);
+    const int pairs = 4 / row_split, rsub = wave / pairs;
+    const int seg0 = blockIdx.y * 8 + 2 * (wave % pairs);          // this wave's segments: seg0, seg0 + 1
+    const int64_t wg_begin = (int64_t)blockIdx.x * rows_per_wg, wg_end = min(wg_begin + rows_per_wg, n_rows);
+    const int64_t sub = ((rows_per_wg / row_split) + 3) / 4 * 4;   // rows of one sub-range (multiple of the 4-row step)
+    const int64_t r_begin = min(wg_begin + rsub * sub, wg_end), r_end = rsub == row_split - 1 ? wg_end : min(r_begin + sub, wg_end);
     f32x4 acc[2][4][NT];
 #pragma unroll
     for (int w2 = 0; w2 < 2; ++w2)
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(kThreads) void dropout_dense_dw_kernel(const float*
         const int64_t row = r0 + kq;
         const bool row_ok = row < r_end;
 #pragma unroll
-        for (int w2 = 0; w2 < 2; ++w2) xa[w2] = load_row4(X, ldx, row_ok ? n_rows : 0, K, row, 64 * (seg0 + 4 * w2) + 4 * i);
+        for (int w2 = 0; w2 < 2; ++w2) xa[w2] = load_row4(X, ldx, row_ok ? n_rows : 0, K, row, 64 * (seg0 + w2) + 4 * i);
 #pragma unroll
         for (int u = 0; u < NT; ++u) gb[u] = (row_ok && 16 * u + i < C) ? G[row * ldg + 16 * u + i] : 0.f;
     };
@@ -312,14 +317,14 @@ __global__ __launch_bounds__(kThreads) void dropout_dense_dw_kernel(const float*
         if (r0 + kDwRowsPerStep < r_end) fetch(r0 + kDwRowsPerStep, xa_n, gb_n);
 #pragma unroll
         for (int w2 = 0; w2 < 2; ++w2) {
-            const f4u xm = apply_mask(xa[w2], mk, r0 + kq, 64 * (seg0 + 4 * w2) + 4 * i, inv_keep);
+            const f4u xm = apply_mask(xa[w2], mk, r0 + kq, 64 * (seg0 + w2) + 4 * i, inv_keep);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int u = 0; u < NT; ++u) acc[w2][j][u] = mfma16(xm[j], gb[u], acc[w2][j][u]);
         }
     }
-    float* out = partial + (int64_t)blockIdx.x * Kp * CP;
+    float* out = partial + ((int64_t)blockIdx.x * row_split + rsub) * Kp * CP;
 #pragma unroll
     for (int w2 = 0; w2 < 2; ++w2)
 #pragma unroll
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void dropout_dense_dw_kernel(const float*
             for (int u = 0; u < NT; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int k = 64 * (seg0 + 4 * w2) + 4 * (4 * kq + r) + j;
+                    const int k = 64 * (seg0 + w2) + 4 * (4 * kq + r) + j;
                     if (k < Kp) out[(int64_t)k * CP + 16 * u + i] = acc[w2][j][u][r];
                 }
 }
@@ -344,7 +349,7 @@ __global__ void reduce_dw_kernel(const float* __restrict__ partial, int n_parts,
 }
 
 struct Shape {
-    int nt, kpad, cp, n_chunks, kp, gy;
+    int nt, kpad, cp, n_chunks, kp, gy, row_split;
     int64_t gx, rows_per_wg;
     size_t off_wfwd, off_wdx, off_partial, total;
 };
@@ -363,17 +368,19 @@ Shape shape_of(int64_t n_rows, int K, int C) {
     s.n_chunks = s.kpad / kKC;
     s.gy = (K + 511) / 512;
     s.kp = s.gy * 512;
+    const int n_pairs = ((K + 63) / 64 + 1) / 2;                       // segment pairs that hold columns of X
+    s.row_split = s.gy > 1 ? 1 : (n_pairs <= 1 ? 4 : (n_pairs == 2 ? 2 : 1));
     // dW: enough workgroups to fill the chip, each over a contiguous row range that is a multiple of 4 rows
     const int64_t want = std::max<int64_t>(1, (int64_t)cu_count() * 2 / s.gy);
     int64_t per = (n_rows + want - 1) / want;
-    per = std::max<int64_t>(64, (per + 3) / 4 * 4);
+    per = std::max<int64_t>(64, (per + 15) / 16 * 16);
     s.rows_per_wg = per;
     s.gx = std::max<int64_t>(1, (n_rows + per - 1) / per);
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     s.off_wfwd = 0;
     s.off_wdx = al((size_t)s.kpad * lds_stride(s.nt) * 4);
     s.off_partial = s.off_wdx + al((size_t)s.n_chunks * s.cp * kDxStride * 4);
-    s.total = s.off_partial + al((size_t)s.gx * s.kp * s.cp * 4);
+    s.total = s.off_partial + al((size_t)s.gx * s.row_split * s.kp * s.cp * 4);
     return s;
 }
 
@@ -478,12 +485,12 @@ int h2gcn_dropout_dense_backward_f32(const float* X, int64_t ldx, int64_t n_rows
         st = with_nt(s.nt, [&](auto nt_c) -> int {
             constexpr int NT = decltype(nt_c)::value;
             hipLaunchKernelGGL((dropout_dense_dw_kernel<NT>), dim3((unsigned)s.gx, (unsigned)s.gy), dim3(kThreads), 0, stream, X, ldx, n_rows, (int)K,
-                               G, ldg, (int)C, inv_keep, thr, mask_on, seed, step_dev, s.rows_per_wg, part, s.kp);
+                               G, ldg, (int)C, inv_keep, thr, mask_on, seed, step_dev, s.rows_per_wg, part, s.kp, s.row_split);
             H2GCN_HIP_TRY(hipGetLastError());
             return H2GCN_OK;
         });
         if (st != H2GCN_OK) return st;
-        hipLaunchKernelGGL(reduce_dw_kernel, dim3((unsigned)std::min(256, (K * C + 255) / 256)), dim3(256), 0, stream, (const float*)part, (int)s.gx,
+        hipLaunchKernelGGL(reduce_dw_kernel, dim3((unsigned)std::min(256, (K * C + 255) / 256)), dim3(256), 0, stream, (const float*)part, (int)s.gx * s.row_split,
                            s.kp, s.cp, (int)K, (int)C, dW);
         H2GCN_HIP_TRY(hipGetLastError());
     }

@@ -459,9 +459,12 @@ class H2GCN(torch.nn.Module):
                     layer = L.SparseDense(width, conf["units"], use_bias=conf["use_bias"], activation="relu" if fuse else None)
                     fuse_relu_into = ind if fuse else None
                     sparse_input = False
-                elif pending_dropout is not None:
-                    # `D0.5-MO`: dropout + dense in one pass over the concat buffer (mask drawn inside the product kernels)
-                    layer = L.DropoutDense(width, conf["units"], conf["use_bias"], pending_dropout)
+                elif pending_dropout is not None or (fused_classifier and conf["units"] <= 64):
+                    # `D0.5-MO`: dropout + dense in one pass over the concat buffer (mask drawn inside the product kernels).
+                    # A dense layer without a dropout in front runs on the same kernels with the mask off: its weight
+                    # gradient X^T G is a reduction over all N rows into a tiny [K, units] result, which general GEMM tiles
+                    # handle badly (products shape, [N,100]^T [N,64]: 3.3 ms stock, 0.5 ms here)
+                    layer = L.DropoutDense(width, conf["units"], conf["use_bias"], pending_dropout or 0.0)
                     pending_dropout = None
                 else:
                     layer = Dense(width, conf["units"], conf["use_bias"])

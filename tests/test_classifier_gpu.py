@@ -138,7 +138,7 @@ def test_model_uses_the_fused_classifier_and_trains():
         torch.manual_seed(5)
         model = H2GCN(setup, input_dim=feats.n_cols, n_hops=2, sparse_input=True, l2_regularize_weight=5e-4, fused_classifier=fused).to(DEV)
         kinds = [type(m).__name__ for m in model.layer_objs]
-        assert ("DropoutDense" in kinds) == fused and ("Dropout" in kinds) != fused
+        assert ("DropoutDense" in kinds) == fused and ("Dropout" in kinds) != fused and ("Dense" in kinds) != fused
         models[fused] = model
         opt = make_optimizer("adam", model.parameters(), 0.01)
         hist = []
