@@ -58,6 +58,16 @@ def test_null_plan_is_an_error_not_a_crash():
     assert L.h2gcn_spmm_workspace_bytes(None, 0, 0, None, 1, 0, 1) == 0
     assert L.h2gcn_ring_count(-1, None, None, None, None, 0, None, None, 0, 0, None, None, 0, None, None, None, 0, None) == _capi.ERR_INVALID_ARGUMENT
     assert L.h2gcn_hop_normalize(4, None, None, 1, None, 0, None, None) == _capi.ERR_INVALID_ARGUMENT
+    # ABI 3: the adjoint with options, row-window rings, the dropout+dense kernels, exchange capture support
+    assert L.h2gcn_spmm_hops_T_opts_f32(None, 0, None, 1, 1, 1, None, 1, None, None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.h2gcn_ring_count_rows(8, 4, 8, None, None, None, None, 0, None, None, 0, 0, None, None, 0, None, None, None, 0, None) == _capi.ERR_INVALID_ARGUMENT
+    assert b"row window" in L.h2gcn_last_error()
+    assert L.h2gcn_hop_normalize_rows(4, None, None, 1, None, 0, None, None, None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.h2gcn_dropout_dense_workspace_bytes(1000, 448, 47) > 0 and L.h2gcn_dropout_dense_workspace_bytes(10, 8, 65) == 0
+    assert L.h2gcn_dropout_dense_f32(None, 8, 10, 8, None, 65, None, 0.5, 1, None, None, 8, None, 0, None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.h2gcn_dropout_dense_f32(None, 8, 10, 8, None, 4, None, 0.0, 1, None, None, 8, None, 0, None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.h2gcn_dropout_dense_backward_f32(None, 8, 10, 8, None, 4, None, 4, 0.5, 1, None, None, 8, None, None, 0, None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.h2gcn_xchg_reset_dependencies(None) == _capi.ERR_INVALID_ARGUMENT
     assert L.h2gcn_xchg_status(None) == _capi.ERR_INVALID_ARGUMENT and L.h2gcn_xchg_allgather_end(None, 0, None) == _capi.ERR_INVALID_ARGUMENT
     out = ctypes.c_void_p()
     assert L.h2gcn_xchg_create(0, 0, 1, 64, 0, 0, ctypes.byref(out)) == _capi.ERR_INVALID_ARGUMENT and not out.value

@@ -1,7 +1,7 @@
 /* capi_demo.c -- the C ABI used from plain C, no Python / torch anywhere: what a native host (or a cgo / JNI /
  * ctypes binding) does.  Builds a 4x4 two-hop CSR by hand, runs the fused forward launch and the adjoint, rebuilds
- * the 2-hop ring with the ring kernels, runs a fused bias+ReLU launch, and checks everything against values worked
- * out by hand.
+ * the 2-hop ring with the ring kernels (whole and as a row window), runs a fused bias+ReLU launch and the dropout+dense
+ * classifier kernel, and checks everything against values worked out by hand.
  *   hipcc -x c ... is not needed: compile as C with gcc, link libamdhip64 + libh2gcn_hip:
  *   gcc -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/capi_demo.c -o capi_demo \
  *       -L h2gcn_amd/csrc -lh2gcn_hip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../h2gcn_amd/csrc' -lm
@@ -130,6 +130,71 @@ int main(void) {
                 for (int j = 0; j < N; ++j) w += A0[i][j] * x[j * D + c];
                 worst = fmax(worst, fabs(fmax(w, 0.0) - y0[i * D + c]));
             }
+    }
+    /* ---- a row WINDOW of the 2-hop ring (what one rank of a row partition builds): rows [2, 4) only ----------------------- */
+    {
+        const int64_t arp[N + 1] = {0, 1, 3, 5, 6};
+        const int64_t* d_arp = to_device(arp, sizeof arp);
+        const int64_t win_rp[3] = {0, 2, 3};                        /* rows 2, 3 of A as a window CSR: {1, 3}, {2} */
+        const int32_t win_ci[3] = {1, 3, 2};
+        const int64_t* d_wrp = to_device(win_rp, sizeof win_rp);
+        const int32_t* d_wci = to_device(win_ci, sizeof win_ci);
+        const int64_t* sub_rp[1] = {d_wrp};
+        const int32_t* sub_ci[1] = {d_wci};
+        size_t sb = h2gcn_ring_scratch_bytes(N);
+        void* scratch = NULL;
+        int64_t* ring_rp = NULL;
+        int32_t* ring_ci = NULL;
+        int64_t nnz2 = -1;
+        HIP(hipMalloc(&scratch, sb));
+        HIP(hipMalloc((void**)&ring_rp, sizeof(int64_t) * 3));
+        HIP(hipMalloc((void**)&ring_ci, sizeof(int32_t) * 4));
+        /* frontier = the window's rows of ring_1, A = the whole pattern, minus the window's ring_1 rows, minus the diagonal */
+        H2(h2gcn_ring_count_rows(N, 2, 2, d_arp, colidx[0], d_wrp, d_wci, 0, NULL, NULL, 0, 1, sub_rp, sub_ci, 1, ring_rp, &nnz2, scratch, sb, NULL));
+        H2(h2gcn_ring_fill_rows(N, 2, 2, d_arp, colidx[0], d_wrp, d_wci, 0, NULL, NULL, 0, 1, sub_rp, sub_ci, 1, ring_rp, ring_ci, scratch, sb, NULL));
+        HIP(hipDeviceSynchronize());
+        int32_t h_ci[2];
+        HIP(hipMemcpy(h_ci, ring_ci, sizeof h_ci, hipMemcpyDeviceToHost));
+        if (nnz2 != 2 || h_ci[0] != 0 || h_ci[1] != 1) { fprintf(stderr, "ring window: nnz %lld cols %d %d\n", (long long)nnz2, h_ci[0], h_ci[1]); return 7; }
+    }
+    /* ---- the classifier side: Z = X W + b through the dropout+dense kernel with the mask off (keep_prob = 1), then with
+     *      keep_prob = 0.5: every output must be a sum over a SUBSET of the terms, each scaled by 2 -------------------------- */
+    {
+        enum { C = 3 };
+        float w[D * C], b[C] = {0.5f, -1.f, 2.f}, z[N * C], z2[N * C];
+        for (int i = 0; i < D * C; ++i) w[i] = 0.25f * (float)((i % 5) - 2);
+        const float* d_w = to_device(w, sizeof w);
+        const float* d_b = to_device(b, sizeof b);
+        float* d_z = NULL;
+        void* ws = NULL;
+        size_t wsb = h2gcn_dropout_dense_workspace_bytes(N, D, C);
+        HIP(hipMalloc((void**)&d_z, sizeof z));
+        HIP(hipMalloc(&ws, wsb));
+        H2(h2gcn_dropout_dense_f32(dx, D, N, D, d_w, C, d_b, 1.0f, 42u, NULL, d_z, C, ws, wsb, NULL));
+        HIP(hipDeviceSynchronize());
+        HIP(hipMemcpy(z, d_z, sizeof z, hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; ++i)
+            for (int c = 0; c < C; ++c) {
+                double want = b[c];
+                for (int k = 0; k < D; ++k) want += x[i * D + k] * w[k * C + c];
+                worst = fmax(worst, fabs(want - z[i * C + c]) / 16.0);
+            }
+        H2(h2gcn_dropout_dense_f32(dx, D, N, D, d_w, C, NULL, 0.5f, 42u, NULL, d_z, C, ws, wsb, NULL));
+        HIP(hipDeviceSynchronize());
+        HIP(hipMemcpy(z2, d_z, sizeof z2, hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; ++i) {                                /* some subset of {0..D-1} must explain the whole row */
+            int found = 0;
+            for (int m = 0; m < (1 << D) && !found; ++m) {
+                int ok = 1;
+                for (int c = 0; c < C && ok; ++c) {
+                    double want = 0;
+                    for (int k = 0; k < D; ++k) if (m & (1 << k)) want += 2.0 * x[i * D + k] * w[k * C + c];
+                    ok = fabs(want - z2[i * C + c]) <= 1e-4;
+                }
+                found = ok;
+            }
+            if (!found) { fprintf(stderr, "dropout row %d is not a masked, rescaled product\n", i); return 8; }
+        }
     }
     /* error channel: a hop mask beyond the plan must fail cleanly */
     int st = h2gcn_spmm_hops_f32(plan, 0x8, dx, D, D, dy, H * D, D, NULL);
