@@ -10,14 +10,19 @@ C ABI of ``include/h2gcn_hip.h``).  It mirrors the reference's operator interfac
 * :mod:`h2gcn_amd.operands` -- construction of the normalised exact-k-hop matrices: on the device with the HIP ring
   kernels (``build_adj_norm_hops_device``) or on the host with scipy as the reference does
   (reference ``h2gcn/datasets/_dataset.py:102-158``);
-* :mod:`h2gcn_amd.partition` -- row partitioning + embedding exchange (RCCL all-gather or the library's IPC pulls) for
-  1..8 GPUs (new; the reference is single-device).
+* :mod:`h2gcn_amd.partition` -- row partitioning (equal or nnz-balanced blocks) + embedding exchange (RCCL all-gather or
+  the library's IPC pulls) for 1..8 GPUs (new; the reference is single-device);
+* :class:`h2gcn_amd.layers.DropoutDense` -- keras ``Dropout`` + output ``Dense`` (``D0.5-MO``) as one pass over the concat
+  buffer per direction (reference ``h2gcn/models/H2GCN.py:235-257``).
+
+Results of the aggregation are bit-reproducible functions of the operands (one canonical summation tree in every kernel):
+any slicing, chunking or row partition gives the same bits.
 
 There is no CPU fallback: every compute entry point raises if the HIP library or a GPU is missing.
 """
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"
 
 from . import _capi  # noqa: F401  (does not load the library until first use)
 from .hops import HopPlan  # noqa: F401
-from .layers import ConcatLayer, GCNLayer, SliceLayer, SparseDense, SparseDropout, hop_spmm  # noqa: F401
+from .layers import ConcatLayer, DropoutDense, GCNLayer, SliceLayer, SparseDense, SparseDropout, hop_spmm  # noqa: F401
