@@ -422,14 +422,14 @@ def main():
     else:
         exchanges = [a.exchange] if a.exchange else os.environ.get(
             "H2GCN_BENCH_EXCHANGES", "allgather,p2p,ipc_engine,ipc_kernel").split(",")
-        # chunks stay >= 64 columns: every such width builds the canonical summation tree, so the checksum of Y is the
-        # same for every candidate and equal to the 1-GPU line's (narrower chunks would also cost +6-12 % SpMM time)
-        chunk_specs = [a.chunks] if a.chunks else ["1", "2", "4"]
+        # every chunk width builds the canonical summation tree, so the checksum of Y is the same for every candidate and
+        # equal to the 1-GPU line's; 32-column chunks (a short exposed head of the exchange) run as masked 64-column slices
+        chunk_specs = [a.chunks] if a.chunks else ["1", "2", "4", "32+32+64"]
         cands = {}
         for ex in exchanges:
             for spec in chunk_specs:
                 widths = parse_chunks(spec, d)
-                if isinstance(widths, int) and (d % widths or (widths > 1 and d // widths < 64)):
+                if isinstance(widths, int) and (d % widths or (widths > 1 and d // widths < 32)):
                     continue
                 if isinstance(widths, list) and sum(widths) != d:
                     continue

@@ -182,24 +182,22 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 // Column-slice width of the EXACT kernels (float4 lanes; any d >= 4, any 4-byte aligned operands: 16-byte global loads
 // and stores only need dword alignment on gfx950; n_slices = ceil(d / slice), a partial last slice is masked in the
 // kernel and the lane that straddles the end of a row whose width is not a multiple of 4 overlaps its neighbour).
-//   * d >= 64: only the widths whose lane geometry yields the canonical summation tree (64 / 128 / 256 columns, see
-//     spmm_kernels.hip.h) -- the largest one that divides d, capped so that the gather working set of one slice
-//     (n_src_rows * slice * 4 B) is friendlier to the 256 MiB Infinity Cache when the whole operand is far beyond it;
-//     widths none of them divides (d = 96, 100, 200 ...): one masked slice of the next power of two up to 256 columns
+// Only three lane geometries exist -- 64 / 128 / 256 columns = 4 / 2 / 1 gathered rows per load instruction -- and all
+// three build the canonical summation tree (spmm_kernels.hip.h):
+//   * the largest width that divides d, capped so that the gather working set of one slice (n_src_rows * slice * 4 B) is
+//     friendlier to the 256 MiB Infinity Cache when the whole operand is far beyond it;
+//   * widths none of them divides (d = 96, 100, 200 ...): one masked slice of the next power of two up to 256 columns
 //     (narrower slices of rows that do not start on a cache line fetch every boundary line twice), the widest slice
 //     beyond that; 64-column slices when every row starts on a line and the operand is far beyond the caches;
-//   * d < 64: narrow slices of 32 / 16 columns (8 / 16 gathered rows per load instruction; their own, wider tree --
-//     no feature chunking ever goes below 64 columns, so this is not observable across partitions).
+//   * d < 64: ONE masked slice of 64 columns.  (Rounds 1-2 had 32- and 16-column kernels with 8 / 16 lane groups for
+//     these widths; the masked 64-column kernel is faster on every one of them -- products d = 32: 4.86 vs 5.14 ms,
+//     d = 48: 8.9 vs 14.7 ms, lowdeg d = 32: 3.0 vs 5.8 ms because the short-row walk becomes available,
+//     profiles/r03_sweep_narrow_widths.txt -- and their wider summation tree was the one exception to the bitwise
+//     guarantee, so they are gone.)
 // `forced` > 0 (plan option / scratch layout) overrides the heuristic.
 int pick_slice_cols(int d, int64_t n_src_rows, int forced, double avg_segment_nnz, bool rows_line_aligned = false) {
     if (forced > 0) return forced;
-    if (d < 64) {
-        if (d % 32 == 0) return 32;
-        if (d % 16 == 0) return 16;
-        int w = 16;
-        while (w < d) w *= 2;
-        return w;
-    }
+    if (d < 64) return 64;
     static const int widths[] = {256, 128, 64};
     for (int w : widths) {
         if (d % w != 0) continue;
@@ -358,10 +356,6 @@ int launch(LaunchParams& p, int variant, bool off32, int forced_slice, int64_t n
         H2GCN_LAUNCH(4, 32, true);
     } else if (slice == 64) {
         H2GCN_LAUNCH(4, 16, true);
-    } else if (slice == 32) {
-        H2GCN_LAUNCH(4, 8, true);
-    } else if (slice == 16) {
-        H2GCN_LAUNCH(4, 4, true);  // 64-byte rows, 16 neighbours per load instruction
     } else {
         H2GCN_LAUNCH(1, 64, false);  // d < 4: generic column-tiled path
     }
@@ -443,9 +437,8 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
                 return fail(H2GCN_ERR_INVALID_ARGUMENT, "opts->struct_size = %u", opts->struct_size);
             memcpy(&o, opts, opts->struct_size);
         }
-        if (o.slice_cols != 0 && o.slice_cols != 16 && o.slice_cols != 32 && o.slice_cols != 64 && o.slice_cols != 128 &&
-            o.slice_cols != 256)
-            return fail(H2GCN_ERR_INVALID_ARGUMENT, "slice_cols = %d, supported 0 (auto), 16, 32, 64, 128, 256", o.slice_cols);
+        if (o.slice_cols != 0 && o.slice_cols != 64 && o.slice_cols != 128 && o.slice_cols != 256)
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "slice_cols = %d, supported 0 (auto), 64, 128, 256", o.slice_cols);
         if (o.long_row_threshold < 0 || o.rows_per_wave < 0 || o.rows_per_wave > h2gcn::kMaxRowsPerWave)
             return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad tunable (long_row_threshold %d, rows_per_wave %d, max %d)",
                         o.long_row_threshold, o.rows_per_wave, h2gcn::kMaxRowsPerWave);

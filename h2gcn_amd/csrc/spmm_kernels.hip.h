@@ -30,8 +30,9 @@
 // same tree over its chunks, the 4 wave totals are added in wave order.)  The bits of Y therefore depend only on the
 // row's own nonzeros and on long_row_threshold -- never on the slice / feature-chunk width, the scratch copy, the
 // segment-walk variant, grid geometry, rows_per_wave or the row partition: a P-GPU run reproduces the 1-GPU result
-// bit-for-bit with ANY chunking (SURVEY.md 8(e) "Determinism").  Only the narrow slices (32 / 16 columns: 8 / 16 lane
-// groups, used for d < 64) have their own wider tree; the launcher never picks them for d >= 64.
+// bit-for-bit with ANY chunking (SURVEY.md 8(e) "Determinism").  There is no exception: widths below 64 columns run on
+// the 64-column geometry with a masked slice (the 32 / 16-column kernels of rounds 1-2, whose 8 / 16 lane groups needed
+// a wider tree, were slower on every width and have been removed).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -72,12 +73,12 @@ constexpr int kMaxTileCols = 256;   // columns one pass of a wave covers at most
 constexpr int kTreeParts = 4;       // partials of the canonical summation tree (see the header comment)
 
 // NP = partials a lane keeps for the canonical tree: the G = 64/LPR lane groups of a wave own G of the 4 partials per
-// step, so a lane cycles through 4/G of them (G >= 4: one -- for G = 4 that IS the canonical tree; G = 8, 16: the
-// narrow-slice tree)
+// step, so a lane cycles through 4/G of them (G = 4: one, G = 2: two, G = 1: all four)
 template <int LPR>
 struct Tree {
     static constexpr int G = kWave / LPR;
-    static constexpr int NP = G >= kTreeParts ? 1 : kTreeParts / G;
+    static_assert(G == 1 || G == 2 || G == 4, "lane geometries: 64 / 128 / 256 columns per slice");
+    static constexpr int NP = kTreeParts / G;
 };
 
 struct HopCsr {

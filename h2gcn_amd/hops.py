@@ -69,9 +69,9 @@ class HopPlan:
         self._handle = C.c_void_p()
         #: let launches use scratch memory for the slice-major copy of X (see h2gcn_spmm_workspace_bytes)
         self.use_workspace = True
-        #: narrowest feature chunk a pipeline may cut (narrower ones would run on the narrow-slice kernels, whose
-        #: summation tree differs from the canonical one)
-        self.min_chunk_cols = 64
+        #: narrowest feature chunk a pipeline may cut: any width gives the same bits (one canonical summation tree in every
+        #: kernel); below 16 columns a chunk is just not worth its extra pass over the indices
+        self.min_chunk_cols = 16
 
         L = _capi.lib()
         arr_t = C.c_void_p * H

@@ -7,7 +7,7 @@ column ids) and the matching rows of the embedding ``X[rows_p, :]``.  ``Y[i, k, 
 ``ncclAllGather`` over xGMI through ``torch.distributed``, backend "nccl"), then the local fused SpMM.  The
 per-row summation tree is canonical (``include/h2gcn_hip.h``, "Floating point"): it depends on the row's own nonzeros
 only, never on the partitioning, the slice width or the feature chunking, so P ranks reproduce the 1-rank result
-bit-for-bit whatever schedule either side picked (feature chunks are kept >= 64 columns wide for that reason).
+bit-for-bit whatever schedule either side picked.
 Everything after the aggregation in H2GCN (concat, dropout, classifier) is row-local; the backward pass needs the
 mirror-image reduce-scatter of ``dX``.
 
@@ -306,9 +306,8 @@ class PipelinedHopAggregation:
 
     The embedding is exchanged in ``n_chunks`` feature-column chunks on a side stream; the fused 1+2-hop SpMM of
     chunk ``c`` (main stream) runs while chunk ``c+1`` is still in flight over xGMI.  Output columns are
-    independent sums and the kernel's per-row summation tree is the same for every chunk width >= 64 columns, so a
-    P-rank run equals the 1-rank run bit-for-bit WHATEVER chunking either of them uses (chunks narrower than 64 columns
-    would run on the narrow-slice kernels, which have their own tree: refused for HIP plans).  Costs: the column ids /
+    independent sums and the kernel's per-row summation tree is the same for every chunk width, so a P-rank run equals
+    the 1-rank run bit-for-bit WHATEVER chunking either of them uses.  Costs: the column ids /
     values are re-read once per chunk (8 B per edge against ``4*d/C`` B of gathered features) and the local shard is
     staged once into chunk-major send buffers.
 
@@ -323,7 +322,7 @@ class PipelinedHopAggregation:
                  group: Optional[dist.ProcessGroup] = None, exchange: str = "allgather",
                  partition: Optional[RowPartition] = None, ipc_timeout_ms: Optional[int] = None):
         """``n_chunks``: number of equal feature chunks, or an explicit list of chunk widths summing to ``d``
-        (e.g. ``[64, 192]``: a narrow first chunk shortens the un-overlapped head of the exchange).
+        (e.g. ``[32, 32, 64]``: a narrow first chunk shortens the un-overlapped head of the exchange).
         ``partition``: the row blocks (default: equal blocks).  With unequal blocks the plan's column ids must already
         live in the padded row space (``RowPartition.to_padded``; ``plan.n_cols == world * per``)."""
         if exchange not in ("allgather", "p2p", "ipc_engine", "ipc_kernel"):
@@ -342,8 +341,7 @@ class PipelinedHopAggregation:
             widths = [d // int(n_chunks)] * int(n_chunks)
         min_cols = int(getattr(plan, "min_chunk_cols", 1))
         if len(widths) > 1 and min(widths) < min_cols:
-            raise ValueError(f"feature chunks {widths}: chunks narrower than {min_cols} columns would leave the canonical "
-                             "summation tree (results would depend on the chunking)")
+            raise ValueError(f"feature chunks {widths}: chunks narrower than {min_cols} columns are not worth their extra pass over the indices")
         self.widths = widths
         self.offsets = [sum(widths[:c]) for c in range(len(widths))]
         self.plan = plan

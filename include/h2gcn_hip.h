@@ -75,10 +75,10 @@ typedef struct h2gcn_plan_opts {
                                     prefetch; 3 = plain wave walk; 4 = default, but never use the slice-major
                                     scratch copy (A/B measurements); 5 = force the short-row mode.  Variants
                                     0, 2, 3, 4, 5 give identical bits.                                          */
-    int32_t slice_cols;          /* feature columns per slice of the slice-major schedule: 16/32/64/128/256,
+    int32_t slice_cols;          /* feature columns per slice of the slice-major schedule: 64 / 128 / 256,
                                     0 = heuristic (narrower slices when X is far beyond the Infinity Cache).
-                                    64, 128 and 256 give identical bits (one canonical summation tree); 16 and
-                                    32 -- picked by the heuristic only for d < 64 -- have their own tree          */
+                                    All three give identical bits (one canonical summation tree); widths
+                                    below 64 columns run as one masked 64-column slice                            */
     int32_t reserved[2];
 } h2gcn_plan_opts;
 
@@ -166,7 +166,7 @@ int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint
  *
  * Floating point: fp32 multiply-add per nonzero in ONE canonical summation tree per output element -- neighbour j of
  * the row (ascending column order, the reference's order after tf.sparse.reorder, _dataset.py:535) is added into
- * partial P[j mod 4], the element is (P0 + P1) + (P2 + P3) -- for every kernel, slice width >= 64, feature chunking,
+ * partial P[j mod 4], the element is (P0 + P1) + (P2 + P3) -- for every kernel, slice width, feature chunking,
  * scratch copy and segment walk (rows with >= long_row_threshold nonzeros: the same tree per wave over the wave's
  * 64-neighbour chunks, wave totals added in order).  The bits of Y depend only on the row's nonzeros, X and
  * long_row_threshold: a row-partitioned multi-GPU run equals the single-GPU run bit-for-bit.

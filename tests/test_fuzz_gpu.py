@@ -30,10 +30,10 @@ def _csr(rng, n_rows, n_cols, mean_deg, heavy, empty_frac):
 
 @settings(max_examples=int(os.environ.get("H2GCN_FUZZ_EXAMPLES", "150")), deadline=None, suppress_health_check=[HealthCheck.too_slow])
 @given(seed=st.integers(0, 2 ** 31 - 1), n_rows=st.integers(1, 700), n_cols=st.integers(1, 700),
-       d=st.sampled_from([1, 2, 5, 8, 16, 32, 48, 64, 96, 128, 160, 256, 320]), n_hops=st.integers(1, 3),
+       d=st.sampled_from([1, 2, 5, 8, 16, 32, 48, 64, 67, 96, 128, 130, 160, 256, 320]), n_hops=st.integers(1, 3),
        mean_deg=st.sampled_from([0.3, 3.0, 20.0, 70.0]), heavy=st.booleans(),
        threshold=st.sampled_from([0, 4, 64, 300]), rpw=st.sampled_from([0, 1, 3, 7]),
-       variant=st.sampled_from([0, 1, 2, 3, 5]), slice_cols=st.sampled_from([0, 16, 32, 64, 128, 256]),
+       variant=st.sampled_from([0, 1, 2, 3, 5]), slice_cols=st.sampled_from([0, 64, 128, 256]),
        mask_bits=st.integers(0, 7))
 def test_random_operands_and_schedules(seed, n_rows, n_cols, d, n_hops, mean_deg, heavy, threshold, rpw, variant,
                                        slice_cols, mask_bits):
@@ -52,8 +52,11 @@ def test_random_operands_and_schedules(seed, n_rows, n_cols, d, n_hops, mean_deg
     mag = og.gcn_layer_f64acc([abs(h) for h in hsel], np.abs(x))
     assert y.shape == want.shape
     assert (np.abs(y - want) <= 1e-5 * np.maximum(1.0, mag)).all()
+    # ... and the bits are those of the library's documented summation tree, whatever schedule the draw picked
+    assert np.array_equal(y, og.gcn_layer_tree(hsel, x, long_threshold=threshold or 256))
     w = rng.uniform(-1, 1, want.shape).astype(np.float32)
     dx = plan.spmm_t(torch.from_numpy(w).to(dev), hops=sel).cpu().numpy()
     want_t = sum(h.T.astype(np.float64) @ w[:, k, :].astype(np.float64) for k, h in enumerate(hsel))
     mag_t = sum(abs(h).T.astype(np.float64) @ np.abs(w[:, k, :]).astype(np.float64) for k, h in enumerate(hsel))
     assert (np.abs(dx - want_t) <= 1e-5 * np.maximum(1.0, mag_t)).all()
+    assert np.array_equal(dx, og.gcn_layer_grad_tree(hsel, w, n_cols, long_threshold=threshold or 256))

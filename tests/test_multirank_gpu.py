@@ -361,7 +361,8 @@ def test_bench_multi_rank_branch_runs_and_matches_one_rank(tmp_path, world):
     assert one["config"]["y_checksum"] == out["config"]["y_checksum"]
     assert one["config"]["nnz_per_hop"] == out["config"]["nnz_per_hop"]
     if world == 2:
-        for extra in (["--chunks", "2"], ["--chunks", "64+64"], ["--slice-cols", "64"], ["--slice-cols", "128"], ["--slice-cols", "256"]):
+        for extra in (["--chunks", "2"], ["--chunks", "64+64"], ["--chunks", "4"], ["--chunks", "16+48+64"], ["--slice-cols", "64"],
+                      ["--slice-cols", "128"], ["--slice-cols", "256"]):
             alt = _run_bench(1, ["--shape", "arxiv", "--steps", "1", "--warmup", "1", "--no-adjoint"] + extra, tmp_path)
             assert alt["config"]["y_checksum"] == out["config"]["y_checksum"], extra
 

@@ -148,7 +148,7 @@ def test_partial_last_slice_widths(d):
     w = rng.uniform(-1, 1, (n, 2, d)).astype(np.float32)
     want = og.gcn_layer_f64acc(hops, x)
     want_t = og.gcn_layer_grad_c(hops, w, n)
-    for sc in (0, 16, 64, 128, 256):
+    for sc in (0, 64, 128, 256):
         for variant in (0, 2):
             plan = HopPlan.from_scipy(hops, dev(), slice_cols=sc, variant=variant, long_row_threshold=128, build_transpose=True)
             ybuf = torch.full((n, 2, d + 12), 7.0, device=dev())          # guard columns right of every hop block
@@ -272,7 +272,8 @@ def test_schedule_heuristics_are_what_the_documentation_says():
     assert s["segment_walk"].startswith("lane group per segment") and s["slice_cols"] == 128
     assert lowdeg_like.schedule(128, adjoint=True)["segment_walk"] in ("wave per segment", "lane group per segment (short rows)",
                                                                        "wave per segment + index prefetch")
-    assert lowdeg_like.schedule(32)["segment_walk"] == "wave per segment + index prefetch"          # slice 32: no short-row kernel
+    s32 = lowdeg_like.schedule(32)                                                      # d < 64: one masked 64-column slice
+    assert s32["slice_cols"] == 64 and s32["n_slices"] == 1 and s32["segment_walk"].startswith("lane group per segment")
     small = plan(3000, 3000, 20, 4)
     assert small.schedule(128)["slice_cols"] == 128 and small.schedule(448)["slice_cols"] == 64 and small.schedule(448)["n_slices"] == 7
 
@@ -428,8 +429,9 @@ def test_rows_per_wave_does_not_change_results(rpw):
 def test_column_slices_do_not_change_results(d):
     """The slice-major schedule (Infinity-Cache-sized column slices inside one launch) re-orders independent output
     columns.  Slice widths 64 / 128 / 256 have different lane geometries (4 / 2 / 1 gathered rows per load) but build
-    the SAME canonical summation tree: bitwise equal results, equal to the oracle's restatement of that tree.  The
-    narrow slices (16 / 32, chosen by the heuristic only for d < 64) agree to rounding."""
+    the SAME canonical summation tree: bitwise equal results, equal to the oracle's restatement of that tree.  Narrower
+    lane geometries do not exist any more (ABI 3: the 16 / 32-column kernels were slower than the masked 64-column slice on
+    every width and had a different tree): asking for them is an argument error."""
     hops = [rand_csr(900, 900, 0.05, 1, empty_frac=0.1), rand_csr(900, 900, 0.1, 2)]
     hops[1] = sp.csr_matrix(sp.vstack([hops[1][:3], sp.csr_matrix(np.full((1, 900), 0.01, dtype=np.float32)), hops[1][4:]]))
     x = np.random.default_rng(1).uniform(-1, 1, (900, d)).astype(np.float32)
@@ -439,14 +441,17 @@ def test_column_slices_do_not_change_results(d):
         for rpw in (0, 2):
             y, plan = run_hip(hops, x, slice_cols=sc, long_row_threshold=512, rows_per_wave=rpw)
             assert np.array_equal(y, tree), (sc, rpw, plan.schedule(d))
-    for sc in (16, 32):
-        y, _ = run_hip(hops, x, slice_cols=sc, long_row_threshold=512)
-        assert_close(y, hops, x)
-        y2, _ = run_hip(hops, x, slice_cols=sc, long_row_threshold=512, rows_per_wave=2)
-        assert np.array_equal(y, y2), sc
+    from h2gcn_amd._capi import H2GCNError
+    for sc in (16, 32, 48):
+        with pytest.raises(H2GCNError, match="slice_cols"):
+            run_hip(hops, x, slice_cols=sc)
+    for dn in (16, 32, 48):    # narrow widths: same tree
+        yn, plan = run_hip(hops, x[:, :dn].copy(), long_row_threshold=512)
+        assert plan.schedule(dn)["slice_cols"] == 64
+        assert np.array_equal(yn, tree[:, :, :dn]), dn
 
 
-@pytest.mark.parametrize("d", [64, 100, 128, 133, 192, 256, 7, 1])
+@pytest.mark.parametrize("d", [64, 100, 128, 133, 192, 256, 7, 1, 16, 32, 48])
 @pytest.mark.parametrize("thr", [0, 20, 100])
 def test_bits_are_the_canonical_tree_for_every_schedule(d, thr):
     """SURVEY.md 8(e) "Determinism": the bits of Y must not depend on how the work was scheduled.  Every segment walk
@@ -476,17 +481,15 @@ def test_bits_are_the_canonical_tree_for_every_schedule(d, thr):
     xt, wt = torch.from_numpy(x).to(dev()), torch.from_numpy(w).to(dev())
     for variant in (0, 2, 3, 5):
         for sc in (0, 64, 128, 256):
-            if sc == 0 and 4 <= d < 64:
-                continue   # below 64 columns the heuristic picks the narrow slices (own tree; never cut by a partition)
             plan = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr, variant=variant, slice_cols=sc)
             for use_ws in (True, False):
                 plan.use_workspace = use_ws
                 assert np.array_equal(plan.spmm(xt).cpu().numpy(), tree), (variant, sc, use_ws, plan.schedule(d))
                 assert np.array_equal(plan.spmm_t(wt).cpu().numpy(), tree_t), (variant, sc, use_ws, "adjoint")
             assert np.array_equal(plan.spmm(xt, hops=[1]).cpu().numpy(), tree[:, 1:]), (variant, sc)
-    plan = HopPlan.from_scipy(hops, dev(), long_row_threshold=thr, slice_cols=0 if d >= 64 or d < 4 else 64)
-    if d >= 128:   # feature chunks of unequal widths (what the multi-GPU pipeline does), written into one output
-        for widths in ([64, d - 64], [d - 64, 64], [d // 2, d - d // 2]):
+    plan = HopPlan.from_scipy(hops, dev(), long_row_threshold=thr)
+    if d >= 32:   # feature chunks of unequal widths (what the multi-GPU pipeline does), written into one output
+        for widths in ([16, d - 16], [d - 16, 16], [d // 2, d - d // 2], [d // 4, d // 4, d - 2 * (d // 4)]):
             y = torch.empty((n, 2, d), device=dev())
             c0 = 0
             for wd in widths:
@@ -494,7 +497,7 @@ def test_bits_are_the_canonical_tree_for_every_schedule(d, thr):
                 c0 += wd
             assert np.array_equal(y.cpu().numpy(), tree), widths
     # a row block (what a rank of the row partition computes) gives the same rows
-    sub = HopPlan.from_scipy([h[400:900] for h in hops], dev(), long_row_threshold=thr, slice_cols=0 if d >= 64 or d < 4 else 64)
+    sub = HopPlan.from_scipy([h[400:900] for h in hops], dev(), long_row_threshold=thr)
     assert np.array_equal(sub.spmm(xt).cpu().numpy(), tree[400:900])
 
 
