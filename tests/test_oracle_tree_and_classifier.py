@@ -1,0 +1,98 @@
+"""CPU suite: the two round-3 restatements in oracle/ that pin BITS of the HIP path -- the canonical summation tree
+(oracle_spmm_tree_f32) and the counter-based dropout mask of the classifier kernels (oracle/classifier.py).  They are
+checked here against independent formulations, so that the GPU suite's bit-exact comparisons rest on something."""
+import numpy as np
+import scipy.sparse as sp
+
+from oracle import classifier as oc
+from oracle import gcn_layer as og
+
+
+def _rand_hops(n, seed, dens=(0.03, 0.2)):
+    rng = np.random.default_rng(seed)
+    hops = []
+    for k, d in enumerate(dens):
+        m = sp.random(n, n, d, format="csr", random_state=seed + k, dtype=np.float32)
+        m.data = rng.uniform(-1, 1, m.nnz).astype(np.float32)
+        m.sort_indices()
+        hops.append(m)
+    return hops
+
+
+def test_tree_restatement_is_a_regrouping_of_the_reference_sum():
+    """Same terms as the reference's sequential loop, only grouped differently: on integer-valued operands (every partial
+    sum exact in fp32) the tree, the sequential C port and scipy agree EXACTLY -- short rows, rows cut into 64-neighbour
+    chunks over four "waves", forward and adjoint; on real-valued operands both are within fp32 round-off of fp64."""
+    n, d = 400, 9
+    rng = np.random.default_rng(1)
+    hops = _rand_hops(n, 3)
+    for h in hops:
+        h.data = rng.integers(-3, 4, h.nnz).astype(np.float32)
+    hops[1] = sp.csr_matrix(sp.vstack([hops[1][:5], sp.csr_matrix(np.ones((1, n), dtype=np.float32)), hops[1][6:]]))   # a 400-nnz row
+    x = rng.integers(-4, 5, (n, d)).astype(np.float32)
+    w = rng.integers(-2, 3, (n, 2, d)).astype(np.float32)
+    want = og.gcn_layer_c(hops, x)
+    want_t = og.gcn_layer_grad_c(hops, w, n)
+    for thr in (8, 64, 256, 100000):
+        assert np.array_equal(og.gcn_layer_tree(hops, x, long_threshold=thr), want), thr
+        assert np.array_equal(og.gcn_layer_grad_tree(hops, w, n, long_threshold=thr), want_t), thr
+    # real-valued: round-off only
+    hops = _rand_hops(n, 7)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    exact = og.gcn_layer_f64acc(hops, x)
+    mag = og.gcn_layer_f64acc([abs(h) for h in hops], np.abs(x))
+    for thr in (8, 256):
+        t = og.gcn_layer_tree(hops, x, long_threshold=thr)
+        assert (np.abs(t - exact) <= 2e-6 * np.maximum(mag, 1.0)).all()
+    assert not np.array_equal(og.gcn_layer_tree(hops, x, 8), og.gcn_layer_tree(hops, x, 256))   # the threshold is part of the tree
+
+
+def test_tree_of_one_row_by_hand():
+    """P[j mod 4] accumulation and (P0 + P1) + (P2 + P3), spelled out with numpy float32 FMAs for one 7-nonzero row."""
+    a = np.array([0.1, -0.7, 0.3, 0.9, -0.2, 0.5, 0.25], dtype=np.float32)
+    xcol = np.array([1.5, -2.25, 0.125, 3.0, -1.0, 0.75, 2.5], dtype=np.float32)
+    m = sp.csr_matrix((a, np.arange(7), [0, 7]), shape=(1, 7))
+    got = og.gcn_layer_tree([m], xcol.reshape(7, 1))[0, 0, 0]
+
+    def fma(p, q, r):   # one rounding: exact in float64 for fp32 inputs of this size, then rounded once
+        return np.float32(np.float64(p) * np.float64(q) + np.float64(r))
+    P = [np.float32(0)] * 4
+    for j in range(7):
+        P[j % 4] = fma(a[j], xcol[j], P[j % 4])
+    assert got == np.float32(np.float32(P[0] + P[1]) + np.float32(P[2] + P[3]))
+
+
+def test_mask_generator_statistics_and_structure():
+    for keep in (0.5, 0.9, 0.25):
+        m = oc.keep_mask(4000, 448, keep, seed=0xDEADBEEF12345, step=3)
+        assert abs(m.mean() - keep) < 2e-3
+        assert np.abs(m.mean(0) - keep).max() < 0.04 and np.abs(m.mean(1) - keep).max() < 0.12   # every column / row
+        assert abs((m[:, :-1] & m[:, 1:]).mean() - keep * keep) < 3e-3                           # neighbours independent
+        assert abs((m[:-1] & m[1:]).mean() - keep * keep) < 3e-3
+    a = oc.keep_mask(100, 30, 0.5, 11, 5)
+    assert np.array_equal(a, oc.keep_mask(100, 30, 0.5, 11, 5))                  # a pure function of (seed, step, index)
+    assert not np.array_equal(a, oc.keep_mask(100, 30, 0.5, 11, 6)) and not np.array_equal(a, oc.keep_mask(100, 30, 0.5, 12, 5))
+    assert np.array_equal(oc.keep_mask(40, 30, 0.5, 11, 5, row0=60), a[60:])     # rows are addressed globally
+    assert oc.keep_mask(5, 7, 1.0, 1, 1).all()
+    # widths that are not multiples of 4: the row's last group is partial, columns beyond it do not exist
+    assert oc.keep_mask(50, 7, 0.5, 1, 1).shape == (50, 7)
+
+
+def test_dropout_dense_gradients_by_finite_differences():
+    rng = np.random.default_rng(0)
+    n, k, c = 30, 13, 5
+    x, w, b = rng.standard_normal((n, k)), rng.standard_normal((k, c)), rng.standard_normal(c)
+    g = rng.standard_normal((n, c))
+    seed, step, keep = 99, 4, 0.7
+    f = lambda xx, ww: float((oc.dropout_dense(xx, ww, b, keep, seed, step) * g).sum())
+    dx, dw, db = oc.dropout_dense_grad(x, w, g, keep, seed, step)
+    eps = 1e-6
+    for (i, j) in ((0, 0), (7, 12), (29, 5)):
+        xp = x.copy(); xp[i, j] += eps
+        assert abs((f(xp, w) - f(x, w)) / eps - dx[i, j]) < 1e-4
+    for (i, j) in ((0, 0), (12, 4), (5, 2)):
+        wp = w.copy(); wp[i, j] += eps
+        assert abs((f(x, wp) - f(x, w)) / eps - dw[i, j]) < 1e-4
+    assert np.allclose(db, g.sum(0))
+    m = oc.keep_mask(n, k, keep, seed, step)
+    assert np.array_equal(dx == 0, ~m)
