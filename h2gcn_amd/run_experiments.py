@@ -107,6 +107,7 @@ def run_epochs(args):
     for callback in obj["pretrain_callbacks"]:
         callback(**tensors)
     started = time.perf_counter()
+    stamps = []
     epoch = 0
     while epoch < args.epochs:  # args.epochs may be lowered by the early-stopping callback
         epoch += 1
@@ -116,10 +117,17 @@ def run_epochs(args):
         obj["epoch_stats"] = {**obj["train_step"](**tensors), **obj["test_step"](**tensors)}
         for callback in obj["post_epoch_callbacks"]:
             callback(epoch, args)
+        stamps.append(time.perf_counter())   # the post-epoch read-back has synchronised the device
     queue = obj["post_train_callbacks"]
     while queue:
         queue.popleft()(args)
     obj["wall_seconds"] = time.perf_counter() - started
+    if epoch > 0 and (not dist.is_initialized() or dist.get_rank() == 0):
+        skip = min(6, epoch // 2)   # first epochs: module loads, allocator growth, hipGraph capture
+        steady = (stamps[-1] - stamps[skip - 1]) / (epoch - skip) * 1e3 if epoch > skip >= 1 else obj["wall_seconds"] / epoch * 1e3
+        obj["steady_ms_per_epoch"] = steady
+        print(f"Epoch loop: {obj['wall_seconds']:.2f} s for {epoch} epochs; steady state {steady:.1f} ms per epoch over the last "
+              f"{epoch - skip} (one training step + one evaluation pass)")
 
 
 if __name__ == "__main__":

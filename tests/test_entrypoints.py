@@ -198,3 +198,18 @@ def test_script_launch_from_the_package_directory():
     pkg = Path(__file__).resolve().parents[1] / "h2gcn_amd"
     r = subprocess.run([sys.executable, "run_experiments.py", "H2GCN", "planetoid", "--help"], cwd=pkg, capture_output=True, text=True)
     assert r.returncode == 0 and "--network_setup" in r.stdout and "--dataset_path" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_synthetic_shape_through_the_entry_point(capsys):
+    """`run_experiments.py H2GCN synthetic --shape arxiv`: BASELINE configs[2]'s shape through the reference-style entry point
+    (operands generated on the device, 2-hop matrix supplied), full-batch H2GCN-2 epochs incl. hipGraph replay."""
+    from h2gcn_amd import run_experiments
+
+    args = run_experiments.main(["H2GCN", "synthetic", "--shape", "arxiv", "--epochs", "6", "--no_feature_normalize", "--classes", "40",
+                                 "--random_seed", "3"])
+    stats = args.objects["epoch_stats"]
+    assert np.isfinite(stats["train_loss"]) and 0.0 <= stats["val_acc"] <= 1.0
+    assert args.objects["tensors"]["adj_hops"].n_rows == 170_000
+    out = capsys.readouterr().out
+    assert "synthetic shape arxiv" in out and "Epoch: 0006" in out
