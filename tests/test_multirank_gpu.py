@@ -419,3 +419,37 @@ def test_bench_eight_ranks_on_one_gpu(tmp_path):
     _keep("bench_shared_gpu_arxiv_n8.json", out)
     one = _run_bench(1, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--no-adjoint"], tmp_path)
     assert one["config"]["y_checksum"] == out["config"]["y_checksum"]
+
+
+SYNTH_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["H2GCN_ROOT"])
+from h2gcn_amd import run_experiments
+args = run_experiments.main(["H2GCN", "synthetic", "--shape", "arxiv", "--classes", "16", "--epochs", "5", "--random_seed", "2", "--no_feature_normalize",
+                             "--network_setup", "M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO"])
+if int(os.environ.get("RANK", "0")) == 0:
+    json.dump({k: float(v) for k, v in args.objects["epoch_stats"].items() if k != "monitor"}, open(os.environ["OUT_FILE"], "w"))
+'''
+
+
+def test_synthetic_shape_row_partitioned_through_the_entry_point(tmp_path):
+    """`run_experiments.py H2GCN synthetic --shape arxiv` under 2 ranks (each generates only its row block of the operands,
+    features and labels; IPC exchange; replayed steps) follows the single-process run."""
+    results = {}
+    for world in (1, 2):
+        port = _free_port()
+        procs = []
+        out_file = tmp_path / f"synth{world}.json"
+        for rank in range(world):
+            env = dict(os.environ, H2GCN_ROOT=str(ROOT), OUT_FILE=str(out_file), H2GCN_EXCHANGE="ipc_kernel")
+            if world > 1:
+                env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                           MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1")
+            else:
+                env.pop("WORLD_SIZE", None)
+            procs.append(subprocess.Popen([sys.executable, "-c", SYNTH_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        results[world] = json.loads(out_file.read_text())
+    for k in ("train_loss", "val_loss", "test_loss"):
+        assert abs(results[1][k] - results[2][k]) <= 2e-3, (k, results[1][k], results[2][k])
