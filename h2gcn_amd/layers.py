@@ -352,6 +352,10 @@ class DropoutDense(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros(units)) if use_bias else None
         self.drop_prob = float(drop_prob)
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0x7FFFFFFFFFFFFFFF
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # row-partitioned runs: the kernels index the mask by LOCAL row, so every rank gets its own stream (otherwise row i
+            # of every shard would be dropped identically)
+            self.seed = (self.seed ^ (torch.distributed.get_rank() * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF
         self.register_buffer("_step", torch.zeros(1, dtype=torch.int64), persistent=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
