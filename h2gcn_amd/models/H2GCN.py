@@ -109,6 +109,11 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
     use_graphs = (not getattr(args, "_no_hipgraph", False) and optimizer.lower() == "adam"
                   and (not sharded or (bool(getattr(hops_obj, "capturable", False))
                                        and os.environ.get("H2GCN_SHARDED_HIPGRAPH", "1") != "0")))
+    # replay pays on launch-bound graphs (Cora: 1.40 -> 0.61 ms per epoch); at the products shape an epoch is 94 ms of
+    # bandwidth-bound kernels either way and the capture itself costs ~2 s of start-up: skip it beyond 2e7 nonzeros
+    plan_obj = getattr(hops_obj, "plan", hops_obj)
+    if use_graphs and plan_obj is not None and sum(getattr(plan_obj, "nnz", [0])) > int(os.environ.get("H2GCN_HIPGRAPH_MAX_NNZ", "20000000")):
+        use_graphs = False
     optimizer = make_optimizer(optimizer, model.parameters(), lr, capturable=use_graphs)
     snapshot = logger.BestSnapshot()
 
