@@ -9,12 +9,16 @@
 // dense classifier", "training loop on device").  With stock kernels this is five passes over the 4.3 GB buffer of the
 // products shape (dropout forward, skinny GEMM, two backward GEMMs, dropout backward: ~15 of a 68 ms step, the GEMMs at
 // 1.1-1.9 TB/s because C = 47 outputs starve a general GEMM tile).  Here every pass streams X (or writes dX) ONCE:
-//   * the dropout mask is a COUNTER-BASED function of (seed, step, row, column) -- two rounds of a 32-bit avalanche hash --
-//     recomputed wherever it is needed instead of stored or applied in a pass of its own;
+//   * the dropout mask is a COUNTER-BASED function of (seed, step, row, column) -- one keyed round of a 32-bit avalanche hash
+//     per group of four elements -- recomputed wherever it is needed instead of stored or applied in a pass of its own;
 //   * the products run on v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain), C padded to 16-column tiles (47 -> 48),
-//     W staged through LDS in 128-row chunks whose layout makes the B-fragment reads 2-way (= full rate) bank accesses;
+//     W staged through LDS in 64-row chunks whose layout makes the B-fragment reads conflict-free;
 //   * dW is accumulated per workgroup in registers over a contiguous row range and reduced in fixed order (deterministic).
-// HBM-bound by design: the MFMA time (0.66 ms at the f32 matrix peak for the products shape) hides under the stream.
+// Where the time goes (products shape, measured by knocking parts out -- tools/classifier_kernels.py): the fp32
+// matrix pipe alone needs 0.84 ms per pass at the clock the chip holds under this load (50.4 M MFMAs x 32 cycles over 1024
+// SIMDs at ~1.9-2.1 GHz; SQ_VALU_MFMA_BUSY_CYCLES confirms the count), the X stream alone 0.86 ms (5 TB/s); the mask VALU work
+// shares the issue port with the MFMAs (+0.1-0.3 ms); the two do not overlap perfectly at 3-4 waves per SIMD:
+// 1.44 / 1.60 / 1.33 ms (forward / dX / dW) = 0.58 / 0.52 / 0.63 of the matrix-pipe floor, 3.0 / 2.7 / 3.2 TB/s of X.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -38,15 +42,25 @@ constexpr int kRowsPerGroup = 4 * kRowsPerWave;
 #define H2GCN_CLS_KC 64
 #endif
 constexpr int kKC = H2GCN_CLS_KC;   // rows of W per LDS chunk (forward) / output columns per chunk (dX): 64 keeps 5 waves per SIMD resident
-constexpr int kDwRowsPerStep = 4;
+#ifndef H2GCN_CLS_DW_SUB
+#define H2GCN_CLS_DW_SUB 1
+#endif
+#ifndef H2GCN_CLS_DW_WG
+#define H2GCN_CLS_DW_WG 3
+#endif
+constexpr int kDwSub = H2GCN_CLS_DW_SUB;       // 4-row reduction sub-steps fetched together (measured: 1 beats 2 and 4, 1.44 vs 2.0 / 1.8 ms)
+constexpr int kDwRowsPerStep = 4 * kDwSub;
 
 __host__ __device__ constexpr int lds_stride(int nt) { return nt == 1 ? 16 : (nt <= 3 ? 48 : 80); }  // floats; stride % 32 == 16
 constexpr int kDxStride = kKC + 16;                                                                      // 80 (144 for 128-column chunks): % 32 == 16
 
 // ---- the mask generator (documented in include/h2gcn_hip.h; the test-side restatement reproduces it bit for bit) -------
-// One hash chain per aligned GROUP of four columns of a row (gid = row * ceil(K/4) + col/4, 64-bit) yields 64 bits, i.e. one
-// 16-bit field per element; an element is kept iff its field < keep_prob * 65536.  (The first version hashed every element
-// separately: 5 quarter-rate v_mul_lo_u32 per element made the VALU work exceed the MFMA work.)
+// One hash per aligned GROUP of four columns of a row (gid = row * ceil(K/4) + col/4, 64-bit): a keyed avalanche round whose
+// second key is injected between its two multiplies.  keep_prob a multiple of 1/256 (0.5, 0.75, 0.9375, ...): the four BYTES
+// of the word are the four elements' fields -- one round, two v_mul_lo_u32 per four elements; any other keep_prob: a second
+// round yields a second word and the fields are 16 bits wide.  (History: hashing every element separately made the VALU work
+// exceed the MFMA work; three rounds per group and a multiply by 1/keep per element still cost 0.29 of 1.15 ms -- the scale
+// is now applied to the finished sums instead.)
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {
     h ^= h >> 16;
     h *= 0x7FEB352Du;
@@ -55,24 +69,29 @@ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
     return h ^ (h >> 16);
 }
 struct MaskKey {
-    uint32_t k0, k1, thr16;
+    uint32_t k0, k1, thr;   // thr: threshold of a field (8-bit fields: keep_prob * 256, 16-bit fields: keep_prob * 65536)
+    int bytes;              // 1: 8-bit fields
     int on;
     int64_t groups_per_row;
 };
 __device__ __forceinline__ MaskKey make_key(uint64_t seed, const int64_t* step_dev, uint32_t thr16, int on, int K) {
     const uint64_t step = (on && step_dev) ? (uint64_t)*step_dev : 0;
-    return MaskKey{(uint32_t)seed ^ ((uint32_t)step * 0x9E3779B9u), (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32), thr16, on, (int64_t)((K + 3) / 4)};
+    const uint32_t k0 = mix32((uint32_t)seed ^ mix32((uint32_t)step + 0x9E3779B9u));
+    const uint32_t k1 = mix32((uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32) ^ k0 ^ 0x85EBCA6Bu);
+    const int bytes = (thr16 & 0xFFu) == 0;
+    return MaskKey{k0, k1, bytes ? thr16 >> 8 : thr16, bytes, on, (int64_t)((K + 3) / 4)};
 }
-// the two hash words of the group holding (row, col): fields (w0 & 0xffff, w0 >> 16, w1 & 0xffff, w1 >> 16) for col % 4 = 0..3
-__device__ __forceinline__ void group_words(const MaskKey& m, int64_t row, int col, uint32_t& w0, uint32_t& w1) {
+// first hash word of the group holding (row, col)
+__device__ __forceinline__ uint32_t group_word(const MaskKey& m, int64_t row, int col) {
     const uint64_t gid = (uint64_t)(row * m.groups_per_row + (col >> 2));
-    const uint32_t h1 = mix32((uint32_t)gid ^ m.k0);
-    w0 = mix32(h1 ^ ((uint32_t)(gid >> 32) * 0x9E3779B9u + m.k1));
-    w1 = mix32(w0 ^ 0x85EBCA6Bu);
-}
-__device__ __forceinline__ bool keep_field(const MaskKey& m, uint32_t w0, uint32_t w1, int j) {
-    const uint32_t w = (j & 2) ? w1 : w0;
-    return ((j & 1) ? (w >> 16) : (w & 0xFFFFu)) < m.thr16;
+    const uint32_t hi = (uint32_t)(gid >> 32);
+    uint32_t h = (uint32_t)gid ^ ((hi << 16) | (hi >> 16)) ^ m.k0;
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= m.k1;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    return h ^ (h >> 16);
 }
 
 // ---- weight packing ------------------------------------------------------------------------------------------------------
@@ -118,15 +137,26 @@ __device__ __forceinline__ f4u load_row4(const float* __restrict__ X, int64_t ld
     }
     return v;
 }
-// dropout of the group (row, k .. k+3): kept elements scaled by 1 / keep_prob
-__device__ __forceinline__ f4u apply_mask(f4u v, const MaskKey& mk, int64_t row, int k, float inv_keep) {
-    if (mk.on) {
-        uint32_t w0, w1;
-        group_words(mk, row, k, w0, w1);
-        v[0] = (w0 & 0xFFFFu) < mk.thr16 ? v[0] * inv_keep : 0.f;
-        v[1] = (w0 >> 16) < mk.thr16 ? v[1] * inv_keep : 0.f;
-        v[2] = (w1 & 0xFFFFu) < mk.thr16 ? v[2] * inv_keep : 0.f;
-        v[3] = (w1 >> 16) < mk.thr16 ? v[3] * inv_keep : 0.f;
+// dropout of the group (row, k .. k+3): dropped elements zeroed.  The 1 / keep_prob scale of the survivors is applied by the
+// callers to the finished sums (forward, dW) or at the store (dX) -- the same value up to one rounding, bit-identical for
+// keep_prob = 0.5
+// MASK: 0 = no dropout (evaluation), 1 = 8-bit fields, 2 = 16-bit fields -- a compile-time mode: a run-time branch inside the
+// unrolled MFMA bodies costs the scheduler its interleaving (measured on the dW kernel: 1.45 -> 1.60 ms)
+template <int MASK>
+__device__ __forceinline__ f4u apply_mask(f4u v, const MaskKey& mk, int64_t row, int k) {
+    if constexpr (MASK == 1) {
+        const uint32_t w0 = group_word(mk, row, k);
+        v[0] = (w0 & 0xFFu) < mk.thr ? v[0] : 0.f;
+        v[1] = ((w0 >> 8) & 0xFFu) < mk.thr ? v[1] : 0.f;
+        v[2] = ((w0 >> 16) & 0xFFu) < mk.thr ? v[2] : 0.f;
+        v[3] = (w0 >> 24) < mk.thr ? v[3] : 0.f;
+    } else if constexpr (MASK == 2) {
+        const uint32_t w0 = group_word(mk, row, k);
+        const uint32_t w1 = mix32(w0 ^ 0x85EBCA6Bu);
+        v[0] = (w0 & 0xFFFFu) < mk.thr ? v[0] : 0.f;
+        v[1] = (w0 >> 16) < mk.thr ? v[1] : 0.f;
+        v[2] = (w1 & 0xFFFFu) < mk.thr ? v[2] : 0.f;
+        v[3] = (w1 >> 16) < mk.thr ? v[3] : 0.f;
     }
     return v;
 }
@@ -134,7 +164,7 @@ __device__ __forceinline__ f4u apply_mask(f4u v, const MaskKey& mk, int64_t row,
 // ---- forward -------------------------------------------------------------------------------------------------------------
 // One workgroup = 4 waves x 32 rows; a wave owns 2 row tiles x NT column tiles of 16x16 accumulators.  W chunks of 128 rows
 // are double-buffered in LDS (one barrier per chunk).
-template <int NT>
+template <int NT, int MASK>
 __global__ __launch_bounds__(kThreads) void dropout_dense_fwd_kernel(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int K,
                                                                      const float* __restrict__ Wp, int Kpad, const float* __restrict__ bias,
                                                                      int C, float inv_keep, uint32_t thr, int mask_on, uint64_t seed,
@@ -155,7 +185,9 @@ __global__ __launch_bounds__(kThreads) void dropout_dense_fwd_kernel(const float
             for (int u = 0; u < NT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < n_chunks; ++c) {
             float* buf = lds + (c & 1) * (kKC * S);
-            // the wave's own X fragments first: their latency runs under the LDS fill and the barrier
+            // the wave's own X fragments first: their latency runs under the LDS fill and the barrier.  (Fetching them a whole
+            // chunk ahead was measured too: the second fragment buffer costs a wave per SIMD, 1.44 -> 1.56 ms; 32-row chunks with
+            // the look-ahead 1.53 ms.)
             f4u a[2][kKC / 16];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -170,8 +202,8 @@ __global__ __launch_bounds__(kThreads) void dropout_dense_fwd_kernel(const float
             __syncthreads();
 #pragma unroll
             for (int g = 0; g < kKC / 16; ++g) {
-                const f4u a0 = apply_mask(a[0][g], mk, row_base + i, c * kKC + 16 * g + 4 * kq, inv_keep);
-                const f4u a1 = apply_mask(a[1][g], mk, row_base + 16 + i, c * kKC + 16 * g + 4 * kq, inv_keep);
+                const f4u a0 = apply_mask<MASK>(a[0][g], mk, row_base + i, c * kKC + 16 * g + 4 * kq);
+                const f4u a1 = apply_mask<MASK>(a[1][g], mk, row_base + 16 + i, c * kKC + 16 * g + 4 * kq);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float* brow = buf + ((g * 4 + j) * 4 + kq) * S + i;
@@ -196,14 +228,14 @@ __global__ __launch_bounds__(kThreads) void dropout_dense_fwd_kernel(const float
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t row = row_base + 16 * t + 4 * kq + r;
-                    if (row < n_rows) Y[row * ldy + col] = acc[t][u][r] + bv;
+                    if (row < n_rows) Y[row * ldy + col] = acc[t][u][r] * inv_keep + bv;
                 }
             }
     }
 }
 
 // ---- backward, data: dX = (G W^T) .* M / keep ---------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int MASK>
 __global__ __launch_bounds__(kThreads) void dropout_dense_dx_kernel(const float* __restrict__ G, int64_t ldg, int64_t n_rows, int K, int C,
                                                                     const float* __restrict__ Wtp, int n_chunks, float inv_keep,
                                                                     uint32_t thr, int mask_on, uint64_t seed, const int64_t* step_dev,
@@ -255,7 +287,10 @@ __global__ __launch_bounds__(kThreads) void dropout_dense_dx_kernel(const float*
                     f4u o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = t == 0 ? acc0[r] : acc1[r];
-                    if (mk.on) o = apply_mask(o, mk, row, col, inv_keep);
+                    if constexpr (MASK != 0) {
+                        o = apply_mask<MASK>(o, mk, row, col);
+                        o *= inv_keep;
+                    }
                     float* dst = dX + row * lddx + col;
                     if (col + 4 <= K) {
                         __builtin_nontemporal_store(o, reinterpret_cast<f4u*>(dst));
@@ -276,8 +311,10 @@ __global__ __launch_bounds__(kThreads) void dropout_dense_dx_kernel(const float*
 // fewer than four pairs) split the workgroup's rows over the otherwise idle waves instead (row_split = 2 or 4 sub-ranges,
 // each with its own partial result).  M index of a tile (segment, j): ii <-> k = 64 seg + 4 ii + j.  The reduction runs over
 // the row range in steps of 4 rows.
-template <int NT>
-__global__ __launch_bounds__(kThreads) void dropout_dense_dw_kernel(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int K,
+// launch bounds: 3 waves per SIMD (2 with four column tiles) -- without them the epilogue's accumulator read-out (96 AGPRs -> VGPRs
+// at once) sets the allocation and the kernel drops to 2 waves per SIMD (measured 1.45 -> 1.76 ms)
+template <int NT, int MASK>
+__global__ __launch_bounds__(kThreads, NT <= 3 ? 3 : 2) void dropout_dense_dw_kernel(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int K,
                                                                     const float* __restrict__ G, int64_t ldg, int C, float inv_keep,
                                                                     uint32_t thr, int mask_on, uint64_t seed, const int64_t* step_dev,
                                                                     int64_t rows_per_wg, float* __restrict__ partial, int Kp, int row_split) {
@@ -288,7 +325,7 @@ __global__ __launch_bounds__(kThreads) void dropout_dense_dw_kernel(const float*
     const int pairs = 4 / row_split, rsub = wave / pairs;
     const int seg0 = blockIdx.y * 8 + 2 * (wave % pairs);          // this wave's segments: seg0, seg0 + 1
     const int64_t wg_begin = (int64_t)blockIdx.x * rows_per_wg, wg_end = min(wg_begin + rows_per_wg, n_rows);
-    const int64_t sub = ((rows_per_wg / row_split) + 3) / 4 * 4;   // rows of one sub-range (multiple of the 4-row step)
+    const int64_t sub = ((rows_per_wg / row_split) + 3) / 4 * 4;   // rows of one sub-range (multiple of 4 rows)
     const int64_t r_begin = min(wg_begin + rsub * sub, wg_end), r_end = rsub == row_split - 1 ? wg_end : min(r_begin + sub, wg_end);
     f32x4 acc[2][4][NT];
 #pragma unroll
@@ -297,32 +334,43 @@ __global__ __launch_bounds__(kThreads) void dropout_dense_dw_kernel(const float*
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int u = 0; u < NT; ++u) acc[w2][j][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // software pipeline: the operands of step s+1 are requested before the 8 * NT MFMAs of step s are issued
-    auto fetch = [&](int64_t r0, f4u (&xa)[2], float (&gb)[NT]) {
-        const int64_t row = r0 + kq;
-        const bool row_ok = row < r_end;
+    // software pipeline: a step covers kDwSub sub-steps of 4 rows; the operands of step s+1 are requested before the
+    // kDwSub * 8 * NT MFMAs of step s are issued (bytes in flight per wave: 2 steps x kDwSub x 2 KiB of X)
+    auto fetch = [&](int64_t r0, f4u (&xa)[kDwSub][2], float (&gb)[kDwSub][NT]) {
 #pragma unroll
-        for (int w2 = 0; w2 < 2; ++w2) xa[w2] = load_row4(X, ldx, row_ok ? n_rows : 0, K, row, 64 * (seg0 + w2) + 4 * i);
+        for (int q = 0; q < kDwSub; ++q) {
+            const int64_t row = r0 + 4 * q + kq;
+            const bool row_ok = row < r_end;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) gb[u] = (row_ok && 16 * u + i < C) ? G[row * ldg + 16 * u + i] : 0.f;
+            for (int w2 = 0; w2 < 2; ++w2) xa[q][w2] = load_row4(X, ldx, row_ok ? n_rows : 0, K, row, 64 * (seg0 + w2) + 4 * i);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) gb[q][u] = (row_ok && 16 * u + i < C) ? G[row * ldg + 16 * u + i] : 0.f;
+        }
     };
-    f4u xa_n[2];
-    float gb_n[NT];
+    f4u xa_n[kDwSub][2];
+    float gb_n[kDwSub][NT];
     if (r_begin < r_end) fetch(r_begin, xa_n, gb_n);
     for (int64_t r0 = r_begin; r0 < r_end; r0 += kDwRowsPerStep) {
-        f4u xa[2] = {xa_n[0], xa_n[1]};
-        float gb[NT];
+        f4u xa[kDwSub][2];
+        float gb[kDwSub][NT];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) gb[u] = gb_n[u];
+        for (int q = 0; q < kDwSub; ++q) {
+            xa[q][0] = xa_n[q][0];
+            xa[q][1] = xa_n[q][1];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) gb[q][u] = gb_n[q][u];
+        }
         if (r0 + kDwRowsPerStep < r_end) fetch(r0 + kDwRowsPerStep, xa_n, gb_n);
 #pragma unroll
-        for (int w2 = 0; w2 < 2; ++w2) {
-            const f4u xm = apply_mask(xa[w2], mk, r0 + kq, 64 * (seg0 + w2) + 4 * i, inv_keep);
+        for (int q = 0; q < kDwSub; ++q)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int w2 = 0; w2 < 2; ++w2) {
+                const f4u xm = apply_mask<MASK>(xa[q][w2], mk, r0 + 4 * q + kq, 64 * (seg0 + w2) + 4 * i);
 #pragma unroll
-                for (int u = 0; u < NT; ++u) acc[w2][j][u] = mfma16(xm[j], gb[u], acc[w2][j][u]);
-        }
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) acc[w2][j][u] = mfma16(xm[j], gb[q][u], acc[w2][j][u]);
+            }
     }
     float* out = partial + ((int64_t)blockIdx.x * row_split + rsub) * Kp * CP;
 #pragma unroll
@@ -334,18 +382,30 @@ __global__ __launch_bounds__(kThreads) void dropout_dense_dw_kernel(const float*
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int k = 64 * (seg0 + w2) + 4 * (4 * kq + r) + j;
-                    if (k < Kp) out[(int64_t)k * CP + 16 * u + i] = acc[w2][j][u][r];
+                    if (k < Kp) out[(int64_t)k * CP + 16 * u + i] = acc[w2][j][u][r] * inv_keep;
                 }
 }
 
-// dW[k][c] = sum over workgroups, in order (deterministic)
-__global__ void reduce_dw_kernel(const float* __restrict__ partial, int n_parts, int Kp, int CP, int K, int C, float* __restrict__ dW) {
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < K * C; t += gridDim.x * blockDim.x) {
+// dW[k][c] = sum over the per-workgroup partials in a fixed order (deterministic): a workgroup owns 64 outputs, its four waves
+// each sum a quarter of the partials in ascending order, the quarters are combined as (q0 + q1) + (q2 + q3)
+__global__ __launch_bounds__(256) void reduce_dw_kernel(const float* __restrict__ partial, int n_parts, int Kp, int CP, int K, int C,
+                                                        float* __restrict__ dW) {
+    __shared__ float quarter[4][64];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + o;
+    float s = 0.f;
+    if (t < K * C) {
         const int k = t / C, c = t - k * C;
-        float s = 0.f;
-        for (int p = 0; p < n_parts; ++p) s += partial[((int64_t)p * Kp + k) * CP + c];
-        dW[t] = s;
+        const int per = (n_parts + 3) / 4;
+        const int p_begin = min(q * per, n_parts), p_end = min(p_begin + per, n_parts);
+        const float* src = partial + (int64_t)k * CP + c;
+        const int64_t stride = (int64_t)Kp * CP;
+#pragma unroll 8
+        for (int p = p_begin; p < p_end; ++p) s += src[p * stride];
     }
+    quarter[q][o] = s;
+    __syncthreads();
+    if (q == 0 && t < K * C) dW[t] = (quarter[0][o] + quarter[1][o]) + (quarter[2][o] + quarter[3][o]);
 }
 
 struct Shape {
@@ -360,6 +420,15 @@ int cu_count() {
     return cus;
 }
 
+// grid of a persistent kernel (workgroups loop over row groups): exactly the workgroups that are resident at once -- a grid
+// larger than that runs its excess as a second, nearly empty round (measured: 6 per CU requested, 5 resident: +25 % time)
+template <typename Kern>
+unsigned persistent_grid(Kern kern, size_t lds_bytes, int64_t n_groups) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, kThreads, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 4;
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_groups, (int64_t)cu_count() * per_cu));
+}
+
 Shape shape_of(int64_t n_rows, int K, int C) {
     Shape s;
     s.nt = (C + 15) / 16;
@@ -371,7 +440,7 @@ Shape shape_of(int64_t n_rows, int K, int C) {
     const int n_pairs = ((K + 63) / 64 + 1) / 2;                       // segment pairs that hold columns of X
     s.row_split = s.gy > 1 ? 1 : (n_pairs <= 1 ? 4 : (n_pairs == 2 ? 2 : 1));
     // dW: enough workgroups to fill the chip, each over a contiguous row range that is a multiple of 4 rows
-    const int64_t want = std::max<int64_t>(1, (int64_t)cu_count() * 2 / s.gy);
+    const int64_t want = std::max<int64_t>(1, (int64_t)cu_count() * H2GCN_CLS_DW_WG / s.gy);   // 3 workgroups per CU: the register budget of the 96 accumulators
     int64_t per = (n_rows + want - 1) / want;
     per = std::max<int64_t>(64, (per + 15) / 16 * 16);
     s.rows_per_wg = per;
@@ -397,13 +466,23 @@ int check_common(const void* X, int64_t ld, int64_t n_rows, int K, const void* W
     return H2GCN_OK;
 }
 
+int mask_mode(float keep_prob) { return keep_prob < 1.f ? ((keep_threshold(keep_prob) & 0xFFu) == 0 ? 1 : 2) : 0; }
+
+// f(integral_constant<NT>, integral_constant<MASK>)
 template <typename F>
-int with_nt(int nt, F&& f) {
+int with_nt_mask(int nt, int mask, F&& f) {
+    auto with_mask = [&](auto nt_c) -> int {
+        switch (mask) {
+            case 0: return f(nt_c, std::integral_constant<int, 0>());
+            case 1: return f(nt_c, std::integral_constant<int, 1>());
+            default: return f(nt_c, std::integral_constant<int, 2>());
+        }
+    };
     switch (nt) {
-        case 1: return f(std::integral_constant<int, 1>());
-        case 2: return f(std::integral_constant<int, 2>());
-        case 3: return f(std::integral_constant<int, 3>());
-        default: return f(std::integral_constant<int, 4>());
+        case 1: return with_mask(std::integral_constant<int, 1>());
+        case 2: return with_mask(std::integral_constant<int, 2>());
+        case 3: return with_mask(std::integral_constant<int, 3>());
+        default: return with_mask(std::integral_constant<int, 4>());
     }
 }
 
@@ -434,11 +513,11 @@ int h2gcn_dropout_dense_f32(const float* X, int64_t ldx, int64_t n_rows, int32_t
     const int mask_on = keep_prob < 1.f ? 1 : 0;
     const size_t lds_bytes = (size_t)2 * kKC * S * 4;
     const int64_t n_groups = (n_rows + kRowsPerGroup - 1) / kRowsPerGroup;
-    const unsigned grid = (unsigned)std::min<int64_t>(n_groups, (int64_t)cu_count() * 6);
-    return with_nt(s.nt, [&](auto nt_c) -> int {
-        constexpr int NT = decltype(nt_c)::value;
-        H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)dropout_dense_fwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL((dropout_dense_fwd_kernel<NT>), dim3(grid), dim3(kThreads), lds_bytes, stream, X, ldx, n_rows, (int)K, (const float*)wp,
+    return with_nt_mask(s.nt, mask_mode(keep_prob), [&](auto nt_c, auto mask_c) -> int {
+        constexpr int NT = decltype(nt_c)::value, MASK = decltype(mask_c)::value;
+        H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)dropout_dense_fwd_kernel<NT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        const unsigned grid = persistent_grid(dropout_dense_fwd_kernel<NT, MASK>, lds_bytes, n_groups);
+        hipLaunchKernelGGL((dropout_dense_fwd_kernel<NT, MASK>), dim3(grid), dim3(kThreads), lds_bytes, stream, X, ldx, n_rows, (int)K, (const float*)wp,
                            s.kpad, bias, (int)C, 1.f / keep_prob, keep_threshold(keep_prob), mask_on, seed, step_dev, Y, ldy);
         H2GCN_HIP_TRY(hipGetLastError());
         return H2GCN_OK;
@@ -469,11 +548,11 @@ int h2gcn_dropout_dense_backward_f32(const float* X, int64_t ldx, int64_t n_rows
         H2GCN_HIP_TRY(hipGetLastError());
         const size_t lds_bytes = (size_t)2 * s.cp * kDxStride * 4;
         const int64_t n_groups = (n_rows + kRowsPerGroup - 1) / kRowsPerGroup;
-        const unsigned grid = (unsigned)std::min<int64_t>(n_groups, (int64_t)cu_count() * 6);
-        st = with_nt(s.nt, [&](auto nt_c) -> int {
-            constexpr int NT = decltype(nt_c)::value;
-            H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)dropout_dense_dx_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            hipLaunchKernelGGL((dropout_dense_dx_kernel<NT>), dim3(grid), dim3(kThreads), lds_bytes, stream, G, ldg, n_rows, (int)K, (int)C,
+        st = with_nt_mask(s.nt, mask_mode(keep_prob), [&](auto nt_c, auto mask_c) -> int {
+            constexpr int NT = decltype(nt_c)::value, MASK = decltype(mask_c)::value;
+            H2GCN_HIP_TRY(hipFuncSetAttribute((const void*)dropout_dense_dx_kernel<NT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            const unsigned grid = persistent_grid(dropout_dense_dx_kernel<NT, MASK>, lds_bytes, n_groups);
+            hipLaunchKernelGGL((dropout_dense_dx_kernel<NT, MASK>), dim3(grid), dim3(kThreads), lds_bytes, stream, G, ldg, n_rows, (int)K, (int)C,
                                (const float*)wtp, s.n_chunks, inv_keep, thr, mask_on, seed, step_dev, dX, lddx);
             H2GCN_HIP_TRY(hipGetLastError());
             return H2GCN_OK;
@@ -482,15 +561,15 @@ int h2gcn_dropout_dense_backward_f32(const float* X, int64_t ldx, int64_t n_rows
     }
     if (dW) {
         float* part = (float*)((char*)workspace + s.off_partial);
-        st = with_nt(s.nt, [&](auto nt_c) -> int {
-            constexpr int NT = decltype(nt_c)::value;
-            hipLaunchKernelGGL((dropout_dense_dw_kernel<NT>), dim3((unsigned)s.gx, (unsigned)s.gy), dim3(kThreads), 0, stream, X, ldx, n_rows, (int)K,
+        st = with_nt_mask(s.nt, mask_mode(keep_prob), [&](auto nt_c, auto mask_c) -> int {
+            constexpr int NT = decltype(nt_c)::value, MASK = decltype(mask_c)::value;
+            hipLaunchKernelGGL((dropout_dense_dw_kernel<NT, MASK>), dim3((unsigned)s.gx, (unsigned)s.gy), dim3(kThreads), 0, stream, X, ldx, n_rows, (int)K,
                                G, ldg, (int)C, inv_keep, thr, mask_on, seed, step_dev, s.rows_per_wg, part, s.kp, s.row_split);
             H2GCN_HIP_TRY(hipGetLastError());
             return H2GCN_OK;
         });
         if (st != H2GCN_OK) return st;
-        hipLaunchKernelGGL(reduce_dw_kernel, dim3((unsigned)std::min(256, (K * C + 255) / 256)), dim3(256), 0, stream, (const float*)part, (int)s.gx * s.row_split,
+        hipLaunchKernelGGL(reduce_dw_kernel, dim3((unsigned)((K * C + 63) / 64)), dim3(256), 0, stream, (const float*)part, (int)s.gx * s.row_split,
                            s.kp, s.cp, (int)K, (int)C, dW);
         H2GCN_HIP_TRY(hipGetLastError());
     }

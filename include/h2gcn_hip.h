@@ -304,13 +304,18 @@ int h2gcn_hop_normalize_rows(int64_t n_rows, const int64_t* rowptr_dev, const in
  *     backward   dX[n, k] = keep(n, k) ? (sum_c G[n, c] * W[k, c]) / keep_prob : 0
  *                dW[k, c] = sum_n D[n, k] * G[n, c]                     (db = column sums of G: left to the caller)
  *
- * The dropout mask is COUNTER-BASED, recomputed wherever it is needed instead of stored.  One hash chain per aligned group
- * of four columns of a row yields four 16-bit fields:
- *     gid = n * ceil(K / 4) + k / 4  (64-bit),   keep(n, k)  <=>  field[k % 4] < keep_prob * 65536,
- *     w0 = mix(mix(lo32(gid) ^ key0) ^ (hi32(gid) * 0x9E3779B9 + key1)),   w1 = mix(w0 ^ 0x85EBCA6B),
- *     field = (w0 & 0xffff, w0 >> 16, w1 & 0xffff, w1 >> 16),
- *     key0 = lo32(seed) ^ (lo32(step) * 0x9E3779B9),  key1 = hi32(seed) ^ hi32(step),
- *     mix(h): h ^= h >> 16; h *= 0x7FEB352D; h ^= h >> 15; h *= 0x846CA68B; h ^= h >> 16   (mod 2^32)
+ * The dropout mask is COUNTER-BASED, recomputed wherever it is needed instead of stored.  One keyed hash per aligned group
+ * of four columns of a row:
+ *     gid = n * ceil(K / 4) + k / 4  (64-bit),
+ *     h = lo32(gid) ^ rotl16(hi32(gid)) ^ key0;  h ^= h >> 16;  h *= 0x7FEB352D;  h ^= key1;  h ^= h >> 15;  h *= 0x846CA68B;
+ *     w0 = h ^ (h >> 16)                                                                              (all mod 2^32)
+ *     key0 = mix(lo32(seed) ^ mix(lo32(step) + 0x9E3779B9)),   key1 = mix(hi32(seed) ^ hi32(step) ^ key0 ^ 0x85EBCA6B),
+ *     mix(h): h ^= h >> 16; h *= 0x7FEB352D; h ^= h >> 15; h *= 0x846CA68B; h ^= h >> 16
+ *   T = floor(keep_prob * 65536).  T a multiple of 256 (keep_prob a multiple of 1/256: 0.5, 0.75, 0.875, ...):
+ *     keep(n, k)  <=>  byte (k % 4) of w0  <  T / 256                                                  (8-bit fields)
+ *   otherwise  w1 = mix(w0 ^ 0x85EBCA6B),  field = (w0 & 0xffff, w0 >> 16, w1 & 0xffff, w1 >> 16),
+ *     keep(n, k)  <=>  field[k % 4] < T                                                                (16-bit fields)
+ * The survivors' 1 / keep_prob scale is applied to the finished sums (Z, dW) or at the store (dX).
  * `step` is read from DEVICE memory (*step_dev; NULL = 0) so that a captured hipGraph draws a fresh mask on every replay
  * (the caller bumps the counter with a stream-ordered op); the backward call must see the value its forward saw.
  * keep_prob = 1 switches the mask off (evaluation).  TensorFlow's stateful RNG stream cannot be reproduced by any other

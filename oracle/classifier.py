@@ -26,20 +26,33 @@ def _mix(h):
 
 
 def keep_mask(n_rows: int, k: int, keep_prob: float, seed: int, step: int, row0: int = 0):
-    """bool [n_rows, k].  One hash chain per aligned GROUP of four columns of a row -- gid = row * ceil(k/4) + col // 4 --
-    yields two 32-bit words = four 16-bit fields; element col is kept iff field[col % 4] < keep_prob * 65536."""
+    """bool [n_rows, k].  One keyed hash per aligned GROUP of four columns of a row -- gid = row * ceil(k/4) + col // 4.
+    keep_prob * 65536 a multiple of 256: the four bytes of the hash word are the elements' fields, kept iff byte <
+    keep_prob * 256; otherwise a second round yields a second word and the fields are 16 bits wide (kept iff field <
+    floor(keep_prob * 65536))."""
     if keep_prob >= 1.0:
         return np.ones((n_rows, k), dtype=bool)
     gpr = (k + 3) // 4
+    thr16 = min(int(np.float32(keep_prob).astype(np.float64) * 65536.0), 65536)
     with np.errstate(over="ignore"):
         gid = (np.arange(row0, row0 + n_rows, dtype=np.uint64)[:, None] * np.uint64(gpr) + np.arange(gpr, dtype=np.uint64)[None, :])
         lo, hi = (gid & np.uint64(0xFFFFFFFF)).astype(np.uint32), (gid >> np.uint64(32)).astype(np.uint32)
-        key0 = np.uint32(seed & 0xFFFFFFFF) ^ (np.uint32(step & 0xFFFFFFFF) * _GOLD)
-        key1 = np.uint32((seed >> 32) & 0xFFFFFFFF) ^ np.uint32((step >> 32) & 0xFFFFFFFF)
-        w0 = _mix(_mix(lo ^ key0) ^ (hi * _GOLD + key1))
-        w1 = _mix(w0 ^ np.uint32(0x85EBCA6B))
-    fields = np.stack([w0 & np.uint32(0xFFFF), w0 >> np.uint32(16), w1 & np.uint32(0xFFFF), w1 >> np.uint32(16)], axis=-1)
-    thr = np.uint32(min(int(keep_prob * 65536.0), 65536))
+        key0 = _mix(np.uint32(seed & 0xFFFFFFFF) ^ _mix(np.uint32(step & 0xFFFFFFFF) + _GOLD))
+        key1 = _mix(np.uint32((seed >> 32) & 0xFFFFFFFF) ^ np.uint32((step >> 32) & 0xFFFFFFFF) ^ key0 ^ np.uint32(0x85EBCA6B))
+        h = lo ^ ((hi << np.uint32(16)) | (hi >> np.uint32(16))) ^ key0
+        h = h ^ (h >> np.uint32(16))
+        h = h * _M1
+        h = h ^ key1
+        h = h ^ (h >> np.uint32(15))
+        h = h * _M2
+        w0 = h ^ (h >> np.uint32(16))
+        if thr16 % 256 == 0:
+            fields = np.stack([(w0 >> np.uint32(8 * j)) & np.uint32(0xFF) for j in range(4)], axis=-1)
+            thr = np.uint32(thr16 // 256)
+        else:
+            w1 = _mix(w0 ^ np.uint32(0x85EBCA6B))
+            fields = np.stack([w0 & np.uint32(0xFFFF), w0 >> np.uint32(16), w1 & np.uint32(0xFFFF), w1 >> np.uint32(16)], axis=-1)
+            thr = np.uint32(thr16)
     return (fields < thr).reshape(n_rows, gpr * 4)[:, :k]
 
 

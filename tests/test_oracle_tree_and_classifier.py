@@ -73,6 +73,11 @@ def test_mask_generator_statistics_and_structure():
     assert np.array_equal(a, oc.keep_mask(100, 30, 0.5, 11, 5))                  # a pure function of (seed, step, index)
     assert not np.array_equal(a, oc.keep_mask(100, 30, 0.5, 11, 6)) and not np.array_equal(a, oc.keep_mask(100, 30, 0.5, 12, 5))
     assert np.array_equal(oc.keep_mask(40, 30, 0.5, 11, 5, row0=60), a[60:])     # rows are addressed globally
+    for keep in (0.5, 0.9):                                                      # 8-bit / 16-bit fields
+        s5, s6 = oc.keep_mask(3000, 448, keep, 77, 5), oc.keep_mask(3000, 448, keep, 77, 6)
+        assert abs((s5 & s6).mean() - keep * keep) < 3e-3                        # consecutive steps independent
+        far = oc.keep_mask(3000, 448, keep, 77, 5, row0=2 ** 33)                 # group ids beyond 32 bits
+        assert abs(far.mean() - keep) < 2e-3 and abs((far & s5).mean() - keep * keep) < 3e-3
     assert oc.keep_mask(5, 7, 1.0, 1, 1).all()
     # widths that are not multiples of 4: the row's last group is partial, columns beyond it do not exist
     assert oc.keep_mask(50, 7, 0.5, 1, 1).shape == (50, 7)
