@@ -23,6 +23,7 @@ ERR_NO_TRANSPOSE = -5
 ERR_INTERNAL = -6
 ERR_EXCHANGE_TIMEOUT = -7
 
+METRICS_MAX_SETS = 4
 XCHG_BLOB_BYTES = 192
 XCHG_COPY_ENGINE = 0
 XCHG_COPY_KERNEL = 1
@@ -57,6 +58,9 @@ EXPORTED_SYMBOLS = (
     "h2gcn_dropout_dense_workspace_bytes",
     "h2gcn_dropout_dense_f32",
     "h2gcn_dropout_dense_backward_f32",
+    "h2gcn_masked_metrics_workspace_bytes",
+    "h2gcn_masked_metrics_f32",
+    "h2gcn_masked_ce_backward_f32",
     "h2gcn_xchg_create",
     "h2gcn_xchg_export",
     "h2gcn_xchg_connect",
@@ -197,6 +201,14 @@ def lib() -> C.CDLL:
     L.h2gcn_dropout_dense_backward_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
                                                    C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                                    C.c_size_t, C.c_void_p]
+    L.h2gcn_masked_metrics_workspace_bytes.restype = C.c_size_t
+    L.h2gcn_masked_metrics_workspace_bytes.argtypes = [C.c_int64]
+    L.h2gcn_masked_metrics_f32.restype = C.c_int
+    L.h2gcn_masked_metrics_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.h2gcn_masked_ce_backward_f32.restype = C.c_int
+    L.h2gcn_masked_ce_backward_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_int64, C.c_void_p]
     L.h2gcn_xchg_create.restype = C.c_int
     L.h2gcn_xchg_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.h2gcn_xchg_export.restype = C.c_int

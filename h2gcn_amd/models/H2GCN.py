@@ -19,6 +19,7 @@ import torch.distributed as dist
 from .. import layers as L
 from ..modules import controller, logger
 from . import Layer, parse_network_setup
+from .. import metrics as fused_metrics
 from ._metrics import masked_accuracy, masked_softmax_cross_entropy
 
 
@@ -128,9 +129,9 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
         return dict(train_loss=train_loss.detach())
 
     # The three masked accuracies and two masked losses of an evaluation (reference ``test_step``, ``:77-107``) share
-    # one argmax / one log-softmax; the normalised masks are static, so the five means are two small mat-vecs instead
-    # of ~45 element-wise and reduction launches -- on Cora-sized graphs the epoch is launch-bound.  Same quantities as
-    # ``masked_accuracy`` / ``masked_softmax_cross_entropy`` per mask (summation order aside).
+    # one read of the logits: on the GPU ONE launch of the library's masked-metrics kernel (``h2gcn_amd/metrics.py``) over the
+    # three (labels, mask / sum(mask)) sets; elsewhere one argmax / one log-softmax and two small mat-vecs.  Same
+    # quantities as ``masked_accuracy`` / ``masked_softmax_cross_entropy`` per mask (summation order aside).
     eval_cache = {}
 
     def _eval_weights(y_train, train_mask, y_val, val_mask, y_test, test_mask):
@@ -147,10 +148,14 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
         model.eval()
         predictions = model(adj, features, adj_hops)
         c = _eval_weights(y_train, train_mask, y_val, val_mask, y_test, test_mask)
-        correct = (predictions.argmax(dim=1).unsqueeze(0) == c["labels_acc"]).to(torch.float32)      # [3, N]
-        acc = (correct * c["w_acc"]).sum(dim=1)                                                       # train / val / test
-        nll = -(c["y_loss"] * torch.log_softmax(predictions, dim=1).unsqueeze(0)).sum(dim=2)          # [2, N]
-        loss = (nll * c["w_loss"]).sum(dim=1)                                                         # val / test
+        if fused_metrics.supported(predictions):
+            loss3, acc = fused_metrics.masked_metrics(predictions, [y_train, y_val, y_test], list(c["w_acc"].unbind(0)))
+            loss = loss3[1:]
+        else:
+            correct = (predictions.argmax(dim=1).unsqueeze(0) == c["labels_acc"]).to(torch.float32)      # [3, N]
+            acc = (correct * c["w_acc"]).sum(dim=1)                                                       # train / val / test
+            nll = -(c["y_loss"] * torch.log_softmax(predictions, dim=1).unsqueeze(0)).sum(dim=2)          # [2, N]
+            loss = (nll * c["w_loss"]).sum(dim=1)                                                         # val / test
         return dict(
             train_acc=acc[0], val_acc=acc[1], test_accuracy=acc[2],
             val_loss=loss[0] + model.regularization_loss(),                          # includes the L2 term (:100)
@@ -274,7 +279,18 @@ def _sharded_steps(model, optimizer):
             mask_sums[key] = t.reshape(())
         return mask_sums[key]
 
+    row_weights = {}
+
+    def global_weights(mask):
+        """mask / sum_global(mask) as fp32 row weights (static: computed once per mask)."""
+        key = (mask.data_ptr(), mask.numel())
+        if key not in row_weights:
+            row_weights[key] = mask.to(torch.float32) / global_mask_sum(mask)
+        return row_weights[key]
+
     def partial_ce(preds, labels, mask):
+        if fused_metrics.supported(preds):
+            return fused_metrics.masked_cross_entropy(preds, labels, global_weights(mask))
         m = mask.to(torch.float32)
         ce = -(labels * torch.log_softmax(preds, dim=1)).sum(dim=1)
         return (ce * m).sum() / global_mask_sum(mask)
@@ -317,9 +333,14 @@ def _sharded_steps(model, optimizer):
         model.eval()
         predictions = model(adj, features, adj_hops)
         reg = model.regularization_loss()
-        parts = torch.stack([partial_acc(predictions, y_train, train_mask), partial_acc(predictions, y_val, val_mask),
-                             partial_acc(predictions, y_test, test_mask), partial_ce(predictions, y_val, val_mask),
-                             partial_ce(predictions, y_test, test_mask)])
+        if fused_metrics.supported(predictions):   # one pass over the local logits for all five quantities
+            loss3, acc3 = fused_metrics.masked_metrics(predictions, [y_train, y_val, y_test],
+                                                       [global_weights(m) for m in (train_mask, val_mask, test_mask)])
+            parts = torch.cat([acc3, loss3[1:]])
+        else:
+            parts = torch.stack([partial_acc(predictions, y_train, train_mask), partial_acc(predictions, y_val, val_mask),
+                                 partial_acc(predictions, y_test, test_mask), partial_ce(predictions, y_val, val_mask),
+                                 partial_ce(predictions, y_test, test_mask)])
         parts = sum_over_ranks(parts, adj_hops)
         return dict(train_acc=parts[0], val_acc=parts[1], test_accuracy=parts[2], val_loss=parts[3] + reg,
                     test_loss=parts[4], monitor=dict())

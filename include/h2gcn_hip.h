@@ -339,6 +339,30 @@ int h2gcn_dropout_dense_backward_f32(const float* X_dev, int64_t ldx, int64_t n_
                                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Masked softmax cross-entropy and masked accuracy (reference h2gcn/models/_metrics.py:8-25; called per mask by train_step /
+ * test_step, h2gcn/models/H2GCN.py:66-74, 77-107) in ONE pass over the logits (h2gcn_amd/csrc/metrics.hip).  A "set" m is a
+ * label matrix Y_m [n_rows, C] (one-hot or all-zero rows; any non-negative rows work) plus a row-weight vector w_m [n_rows]
+ * -- the reference's `mask / mean(mask) / n_rows`, i.e. mask / sum(mask); a row-partitioned run divides by the GLOBAL sum:
+ *
+ *     loss[m] = sum_n w_m[n] * ( - sum_c Y_m[n, c] * log_softmax(Z[n])[c] )
+ *     acc[m]  = sum_n w_m[n] * [ argmax_c Z[n, c] == argmax_c Y_m[n, c] ]          (first maximum on ties)
+ *
+ * Rows whose weight is zero in every set are not read; a label matrix is read only at the rows of non-zero weight.  Per-row
+ * terms are fp32, the sums over rows run in fp64 per workgroup and are combined in a fixed order (deterministic).
+ * h2gcn_masked_ce_backward_f32 is the gradient of loss (one set) with respect to Z, times the scalar *gscale_dev (NULL = 1):
+ *     dZ[n, c] = g * w[n] * ( softmax(Z[n])[c] * sum_c' Y[n, c'] - Y[n, c] )     (rows of weight 0: zeros).
+ *   Z  fp32 [n_rows, C] row stride ldz, C <= 64      Y, ldy, w  HOST arrays of n_sets (<= H2GCN_METRICS_MAX_SETS) device pointers /
+ *   strides      loss_out, acc_out  DEVICE fp32 [n_sets] (acc_out may be NULL)      workspace  h2gcn_masked_metrics_workspace_bytes(n_rows)
+ */
+#define H2GCN_METRICS_MAX_SETS 4
+size_t h2gcn_masked_metrics_workspace_bytes(int64_t n_rows);
+int h2gcn_masked_metrics_f32(const float* Z_dev, int64_t ldz, int64_t n_rows, int32_t c, int32_t n_sets, const float* const* Y_dev,
+                             const int64_t* ldy, const float* const* w_dev, float* loss_out_dev, float* acc_out_dev,
+                             void* workspace_dev, size_t workspace_bytes, void* stream);
+int h2gcn_masked_ce_backward_f32(const float* Z_dev, int64_t ldz, int64_t n_rows, int32_t c, const float* Y_dev, int64_t ldy,
+                                 const float* w_dev, const float* gscale_dev, float* dZ_dev, int64_t lddz, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Row-shard exchange between the GPUs of one node (no counterpart in the reference: it is single-process,
  * single-device -- SURVEY.md 8(e) adds the row partition).  Before a hop aggregation every rank needs the whole
  * embedding X[N, d] while it owns only X[rows_p, :]; this object performs that all-gather WITHOUT a collective
