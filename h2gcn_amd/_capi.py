@@ -89,6 +89,7 @@ class PlanOpts(C.Structure):
 
 
 LAUNCH_RELU = 0x1
+LAUNCH_ACCUMULATE = 0x2
 
 
 class LaunchOpts(C.Structure):

@@ -305,7 +305,7 @@ int launch(LaunchParams& p, int variant, bool off32, int forced_slice, int64_t n
     const Schedule sc = decide(variant, exact_ok, p.d, p.rows_per_wave, p.n_sel, forced_slice, n_src_rows, avg_segment_nnz,
                                rows_line_aligned);
     // general store (bias / ReLU epilogue, element-wise tail of a width that is not a multiple of 4): dedicated instantiations
-    const bool gen = p.d % 4 != 0 || p.bias != nullptr || p.relu != 0;
+    const bool gen = p.d % 4 != 0 || p.bias != nullptr || p.relu != 0 || p.accumulate != 0;
     // short-row kernels: shallow fallback batches (more waves per SIMD) once the gather source is far beyond the caches
     const bool short_fb4 = (double)n_src_rows * p.d * 4.0 >= 512.0 * 1024 * 1024;
     const bool pipe = sc.pipe && !gen, scalar128 = sc.scalar128, exact = sc.exact, shortrow = sc.shortrow && !gen;
@@ -679,7 +679,7 @@ int read_launch_opts(const h2gcn_launch_opts* lopts, h2gcn_launch_opts* lo) {
             return fail(H2GCN_ERR_INVALID_ARGUMENT, "launch opts struct_size = %u", lopts->struct_size);
         memcpy(lo, lopts, lopts->struct_size);
     }
-    if (lo->flags & ~(uint32_t)H2GCN_LAUNCH_RELU) return fail(H2GCN_ERR_INVALID_ARGUMENT, "unknown launch flags 0x%x", lo->flags);
+    if (lo->flags & ~(uint32_t)(H2GCN_LAUNCH_RELU | H2GCN_LAUNCH_ACCUMULATE)) return fail(H2GCN_ERR_INVALID_ARGUMENT, "unknown launch flags 0x%x", lo->flags);
     return H2GCN_OK;
 }
 }  // namespace
@@ -691,6 +691,7 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
         h2gcn_launch_opts lo;
         int st = read_launch_opts(lopts, &lo);
         if (st != H2GCN_OK) return st;
+        if (lo.flags & ~H2GCN_LAUNCH_RELU) return fail(H2GCN_ERR_INVALID_ARGUMENT, "forward launch flags 0x%x: only H2GCN_LAUNCH_RELU applies", lo.flags);
         if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
         uint32_t mask;
         st = resolve_mask(plan, hop_mask, &mask);
@@ -762,7 +763,8 @@ int h2gcn_spmm_hops_T_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, cons
         h2gcn_launch_opts lo;
         int st = read_launch_opts(lopts, &lo);
         if (st != H2GCN_OK) return st;
-        if (lo.bias_dev || lo.flags) return fail(H2GCN_ERR_INVALID_ARGUMENT, "the adjoint launch has no epilogue (bias / flags must be 0)");
+        if (lo.bias_dev || (lo.flags & ~H2GCN_LAUNCH_ACCUMULATE))
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "the adjoint launch has no bias / activation epilogue (only H2GCN_LAUNCH_ACCUMULATE is accepted)");
         if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
         if (!plan->has_transpose)
             return fail(H2GCN_ERR_NO_TRANSPOSE, "plan was created without H2GCN_PLAN_BUILD_TRANSPOSE");
@@ -796,6 +798,7 @@ int h2gcn_spmm_hops_T_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, cons
         p.ld_src = ldg_row;
         p.dst = dX;
         p.ld_dst = ldx;
+        p.accumulate = (lo.flags & H2GCN_LAUNCH_ACCUMULATE) ? 1 : 0;
         st = get_long_list(plan, true, mask, &p.long_list, &p.n_long);
         if (st != H2GCN_OK) return st;
         p.long_threshold = plan->long_threshold;

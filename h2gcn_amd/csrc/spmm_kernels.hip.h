@@ -112,6 +112,7 @@ struct LaunchParams {
     int64_t blocks_per_slice;  // n_long + 8 * tiles_per_xcd
     const float* bias;         // optional epilogue: dst = act(sum + bias[col]); NULL = none
     int relu;                  // optional epilogue: act = max(., 0)
+    int accumulate;            // general-store kernels: dst += sum instead of dst = sum (adjoint into an existing gradient)
 };
 
 template <int VEC>
@@ -449,7 +450,18 @@ __device__ __forceinline__ void store_vec(float* p, const float (&acc)[VEC]) {
 template <int VEC, bool GEN, typename P>
 __device__ __forceinline__ void store_out(const P& p, float* row, int col0, int ecol, float (&tot)[VEC]) {
     if (col0 + VEC <= p.d) {
-        if constexpr (GEN) epilogue<VEC>(tot, p.bias, p.relu, col0);
+        if constexpr (GEN) {
+            if (p.accumulate) {
+                if constexpr (VEC == 1) {
+                    tot[0] += row[col0];
+                } else {
+                    const typename VecT<VEC>::type old = *reinterpret_cast<const typename VecT<VEC>::type*>(row + col0);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) tot[i] += old[i];
+                }
+            }
+            epilogue<VEC>(tot, p.bias, p.relu, col0);
+        }
         store_vec<VEC>(row + col0, tot);
         return;
     }
@@ -460,6 +472,7 @@ __device__ __forceinline__ void store_out(const P& p, float* row, int col0, int 
                 const int c = ecol + i;
                 if (c >= col0 && c < p.d) {
                     float t = tot[i];
+                    if (p.accumulate) t += row[c];
                     if (p.bias) t += p.bias[c];
                     if (p.relu) t = fmaxf(t, 0.f);
                     __builtin_nontemporal_store(t, row + c);
@@ -556,11 +569,12 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? (FB == 4 && !SUM ? H2GCN_S
                 float t = partial[0][c];
 #pragma unroll
                 for (int w = 1; w < kWavesPerBlock; ++w) t += partial[w][c];
+                const int64_t off = row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_first]) + col0 + c;
                 if constexpr (EPI) {
+                    if (p.accumulate) t += p.dst[off];
                     if (p.bias) t += p.bias[col0 + c];
                     if (p.relu) t = fmaxf(t, 0.f);
                 }
-                const int64_t off = row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_first]) + col0 + c;
                 __builtin_nontemporal_store(t, p.dst + off);
             }
             if (!EXACT) __syncthreads();

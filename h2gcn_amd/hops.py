@@ -212,8 +212,10 @@ class HopPlan:
         _capi.check(st)
         return out
 
-    def spmm_t(self, grad: torch.Tensor, hops=None) -> torch.Tensor:
-        """Adjoint: ``dx[j, :] = sum_s sum_i A_s[i, j] * grad[i, s, :]`` -> ``[n_cols, d]``."""
+    def spmm_t(self, grad: torch.Tensor, hops=None, out: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
+        """Adjoint: ``dx[j, :] = sum_s sum_i A_s[i, j] * grad[i, s, :]`` -> ``[n_cols, d]``.  ``out``: write into this
+        ``[n_cols, d]`` tensor (unit column stride, any row stride) instead of a new one; ``accumulate=True`` ADDS the
+        result to what ``out`` holds (``H2GCN_LAUNCH_ACCUMULATE``: the `+=` of a gradient slot fused into the store)."""
         _require(self.has_transpose, "plan was built without build_transpose=True; backward is unavailable")
         h_sel = self.n_selected(hops)
         _require(grad.dim() == 3 and grad.shape[0] == self.n_rows and grad.shape[1] == h_sel,
@@ -222,7 +224,14 @@ class HopPlan:
         d = int(grad.shape[2])
         if grad.stride(2) != 1 or grad.stride(0) < d or (h_sel > 1 and grad.stride(1) < d):
             grad = grad.contiguous()  # e.g. an expanded (stride-0) gradient coming out of a reduction
-        dx = torch.empty((self.n_cols, d), dtype=torch.float32, device=self.device)
+        if out is None:
+            _require(not accumulate, "accumulate=True needs the tensor to accumulate into (out=)")
+            dx = torch.empty((self.n_cols, d), dtype=torch.float32, device=self.device)
+        else:
+            _require(out.shape == (self.n_cols, d) and out.dtype == torch.float32 and out.device == self.device
+                     and (out.stride(1) == 1 or d == 1) and (out.stride(0) >= d or self.n_cols <= 1),
+                     f"out must be float32 [{self.n_cols}, {d}] on the plan's device with unit column stride")
+            dx = out
         if self.n_cols == 0:
             return dx
         L = _capi.lib()
@@ -233,12 +242,12 @@ class HopPlan:
             # scratch: slice-major copy of the stacked gradient (same rules as the forward launch)
             ws_bytes = int(L.h2gcn_spmm_workspace_bytes(self._handle, mask, 1, C.c_void_p(grad.data_ptr()), ld_row, ld_hop, d)) if self.use_workspace else 0
             opts = None
-            if ws_bytes:
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
-                opts = _capi.LaunchOpts(struct_size=C.sizeof(_capi.LaunchOpts), flags=0, workspace=ws.data_ptr(),
-                                        workspace_bytes=ws_bytes, bias=None)
+            if ws_bytes or accumulate:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device) if ws_bytes else None
+                opts = _capi.LaunchOpts(struct_size=C.sizeof(_capi.LaunchOpts), flags=_capi.LAUNCH_ACCUMULATE if accumulate else 0,
+                                        workspace=ws.data_ptr() if ws is not None else None, workspace_bytes=ws_bytes, bias=None)
             st = L.h2gcn_spmm_hops_T_opts_f32(self._handle, mask, C.c_void_p(grad.data_ptr()), ld_row, ld_hop, d,
-                                              C.c_void_p(dx.data_ptr()), dx.stride(0),
+                                              C.c_void_p(dx.data_ptr()), dx.stride(0) if self.n_cols > 1 else d,
                                               C.byref(opts) if opts is not None else None, C.c_void_p(stream))
         _capi.check(st)
         return dx

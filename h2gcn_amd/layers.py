@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import Iterable, Optional
 
+import os
+
 import torch
 
 from .hops import HopPlan
@@ -243,10 +245,20 @@ class _FusedPropagation(torch.autograd.Function):
         plan, K, widths, off = ctx.plan, ctx.rounds, ctx.widths, ctx.off
         H = plan.n_hops
         g_k = grad[:, off[K]:off[K] + widths[K]]  # d r_K: a view, read in place by the adjoint launch
+        # The adjoint of round k is ADDED to the slot of r_{k-1} inside the incoming gradient itself (the library's
+        # accumulate flag: the `+=` rides on the adjoint's store) when that tensor is an ordinary dense one nobody else
+        # reads -- the gradient autograd hands to a backward is a temporary -- and the plan is in the wave-per-segment regime
+        # (the accumulating launch has no short-row variant).  Otherwise: a fresh tensor per round plus one `+=` pass.
+        dense = grad.is_contiguous() and isinstance(plan, HopPlan) and os.environ.get("H2GCN_BACKWARD_IN_PLACE", "1") != "0"
         for k in range(K, 0, -1):
-            g_prev = plan.spmm_t(g_k.unflatten(1, (H, widths[k - 1])))
-            g_prev += grad[:, off[k - 1]:off[k - 1] + widths[k - 1]]
-            g_k = g_prev
+            slot = grad[:, off[k - 1]:off[k - 1] + widths[k - 1]]
+            in_place = dense and plan.schedule(widths[k - 1], ld_src=grad.stride(0), adjoint=True)["segment_walk"] == "wave per segment"
+            if in_place:
+                g_k = plan.spmm_t(g_k.unflatten(1, (H, widths[k - 1])), out=slot, accumulate=True)
+            else:
+                g_prev = plan.spmm_t(g_k.unflatten(1, (H, widths[k - 1])))
+                g_prev += slot
+                g_k = g_prev
         return g_k, None, None
 
 

@@ -195,6 +195,7 @@ int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float
  *   is only inspected (do its rows start on 128-byte cache lines?), never dereferenced.
  */
 #define H2GCN_LAUNCH_RELU 0x1u
+#define H2GCN_LAUNCH_ACCUMULATE 0x2u   /* adjoint only: dX += A^T dY instead of dX = A^T dY (see h2gcn_spmm_hops_T_opts_f32) */
 typedef struct h2gcn_launch_opts {
     uint32_t struct_size;      /* = sizeof(h2gcn_launch_opts)                                               */
     uint32_t flags;            /* H2GCN_LAUNCH_*                                                             */
@@ -221,9 +222,15 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
  */
 int h2gcn_spmm_hops_T_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* dY_dev, int64_t ldg_row,
                           int64_t ldg_hop, int32_t d, float* dX_dev, int64_t ldx, void* stream);
-/* The adjoint with options: only workspace_dev / workspace_bytes are used (bias_dev and flags must be 0).  With
+/* The adjoint with options: workspace_dev / workspace_bytes and the flag H2GCN_LAUNCH_ACCUMULATE (bias_dev must be NULL).  With
  * scratch the stacked gradient is copied slice-major per hop when its rows are wide (d > 256) and not cache-line
- * aligned on an operand far beyond the caches -- same bits as the plain launch. */
+ * aligned on an operand far beyond the caches -- same bits as the plain launch.
+ * H2GCN_LAUNCH_ACCUMULATE: dX[j, c] += sum ... -- the adjoint's result is ADDED to what dX holds, each element as
+ * `old + sum` with `sum` the canonical-tree value of the plain launch.  This is the backward of the concat-free propagation:
+ * the gradient slot of r_{k-1} inside the [N, 448] gradient of the representation already holds the classifier's
+ * contribution, and the round's adjoint lands on top of it without a separate `+=` pass (h2gcn/models/_layers.py:90-96 is the
+ * concat whose gradient this adds up).  dX must not overlap dY.  Runs on the general-store kernels (no short-row / index
+ * prefetch variants): meant for the wave-per-segment regime (see h2gcn_plan_schedule). */
 int h2gcn_spmm_hops_T_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* dY_dev, int64_t ldg_row,
                                int64_t ldg_hop, int32_t d, float* dX_dev, int64_t ldx,
                                const h2gcn_launch_opts* opts, void* stream);

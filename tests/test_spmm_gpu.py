@@ -701,6 +701,59 @@ def test_adjoint_matches_oracle(d):
     assert np.abs(dx1 - og.gcn_layer_grad_c(hops[1:], dy[:, 1:2].copy(), 500)).max() <= 2e-5
 
 
+@pytest.mark.parametrize("d", [64, 128, 67, 3, 200])
+@pytest.mark.parametrize("thr", [16, 100000])
+def test_adjoint_accumulates_into_an_existing_gradient(d, thr):
+    """H2GCN_LAUNCH_ACCUMULATE: dX += A^T dY lands on top of what dX holds -- each element `old + sum` with `sum` the bits of
+    the plain launch -- through strided outputs (a column slot of a wider gradient buffer), long and short rows, odd widths."""
+    from h2gcn_amd import HopPlan
+
+    hops = [rand_csr(700, 500, 0.05, 1, empty_frac=0.1), rand_csr(700, 500, 0.1, 2)]
+    rng = np.random.default_rng(5)
+    dy = torch.from_numpy(rng.uniform(-1, 1, (700, 2, d)).astype(np.float32)).to(dev())
+    plan = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr)
+    plain = plan.spmm_t(dy)
+    wide = torch.from_numpy(rng.uniform(-1, 1, (500, d + 9)).astype(np.float32)).to(dev())
+    before = wide.clone()
+    slot = wide[:, 5:5 + d]
+    got = plan.spmm_t(dy, out=slot, accumulate=True)
+    assert got.data_ptr() == slot.data_ptr()
+    assert torch.equal(slot, before[:, 5:5 + d] + plain)                                # bit for bit
+    assert torch.equal(wide[:, :5], before[:, :5]) and torch.equal(wide[:, 5 + d:], before[:, 5 + d:])   # neighbours untouched
+    # out= without accumulate overwrites
+    plan.spmm_t(dy, out=slot)
+    assert torch.equal(slot, plain)
+    with pytest.raises(ValueError):
+        plan.spmm_t(dy, accumulate=True)
+    with pytest.raises(ValueError):
+        plan.spmm_t(dy, out=wide[:, :d + 1], accumulate=True)
+
+
+def test_fused_propagation_backward_in_place_is_bitwise_the_out_of_place_one(monkeypatch):
+    """The concat-free propagation's backward adds each round's adjoint into the slot of the incoming gradient (accumulate
+    flag) -- same bits as a fresh tensor per round plus a `+=` pass, and the incoming gradient's other columns are left alone."""
+    from h2gcn_amd import HopPlan, layers
+
+    n = 900
+    hops = [rand_csr(n, n, 0.04, 3, empty_frac=0.05), rand_csr(n, n, 0.08, 4)]
+    plan = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=64)
+    assert plan.schedule(64, ld_src=448, adjoint=True)["segment_walk"] == "wave per segment"
+    rng = np.random.default_rng(9)
+    r0 = torch.from_numpy(rng.uniform(-1, 1, (n, 64)).astype(np.float32)).to(dev())
+    gout = torch.from_numpy(rng.uniform(-1, 1, (n, 448)).astype(np.float32)).to(dev())
+    grads = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("H2GCN_BACKWARD_IN_PLACE", mode)
+        x = r0.clone().requires_grad_(True)
+        buf = layers.fused_propagation(plan, x, 2)
+        g = gout.clone()
+        buf.backward(g)
+        grads[mode] = x.grad.clone()
+        if mode == "1":
+            assert torch.equal(g[:, :256], gout[:, :256])      # d r_2 is only read
+    assert torch.equal(grads["1"], grads["0"])
+
+
 def test_device_and_host_transposition_agree():
     """The device radix-sort transposition and the host counting sort build the same canonical A^T: the adjoint
     launch gives identical bits on either."""
