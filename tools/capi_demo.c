@@ -196,6 +196,46 @@ int main(void) {
             if (!found) { fprintf(stderr, "dropout row %d is not a masked, rescaled product\n", i); return 8; }
         }
     }
+    /* ---- masked cross-entropy / accuracy of logits Z = x (first 3 columns) against one-hot labels, one set, then its gradient --- */
+    {
+        enum { C = 3 };
+        float zl[N * C], yl[N * C], wl[N], out[2], dz[N * C];
+        double want_loss = 0, want_acc = 0;
+        for (int i = 0; i < N; ++i) {
+            int lab = i % C, arg = 0;
+            double se = 0;
+            for (int c = 0; c < C; ++c) { zl[i * C + c] = x[i * D + c] * 3.f; yl[i * C + c] = c == lab ? 1.f : 0.f; }
+            for (int c = 0; c < C; ++c) { se += exp((double)zl[i * C + c]); if (zl[i * C + c] > zl[i * C + arg]) arg = c; }
+            wl[i] = i == 1 ? 0.f : 1.f / (float)(N - 1);             /* row 1 is outside the mask */
+            want_loss += wl[i] * (log(se) - zl[i * C + lab]);
+            want_acc += wl[i] * (arg == lab);
+        }
+        const float* d_zl = to_device(zl, sizeof zl);
+        const float* d_yl = to_device(yl, sizeof yl);
+        const float* d_wl = to_device(wl, sizeof wl);
+        float *d_out = NULL, *d_dz = NULL;
+        void* ws = NULL;
+        size_t wsb = h2gcn_masked_metrics_workspace_bytes(N);
+        HIP(hipMalloc((void**)&d_out, sizeof out));
+        HIP(hipMalloc((void**)&d_dz, sizeof dz));
+        HIP(hipMalloc(&ws, wsb));
+        const float* ys[1] = {d_yl};
+        const float* ws_rows[1] = {d_wl};
+        const int64_t ldys[1] = {C};
+        H2(h2gcn_masked_metrics_f32(d_zl, C, N, C, 1, ys, ldys, ws_rows, d_out, d_out + 1, ws, wsb, NULL));
+        H2(h2gcn_masked_ce_backward_f32(d_zl, C, N, C, d_yl, C, d_wl, NULL, d_dz, C, NULL));
+        HIP(hipDeviceSynchronize());
+        HIP(hipMemcpy(out, d_out, sizeof out, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(dz, d_dz, sizeof dz, hipMemcpyDeviceToHost));
+        worst = fmax(worst, fabs(out[0] - want_loss));
+        worst = fmax(worst, fabs(out[1] - want_acc));
+        for (int i = 0; i < N; ++i) {                                 /* dZ = w (softmax - y); rows sum to zero; masked-out row is zero */
+            double rs = 0;
+            for (int c = 0; c < C; ++c) rs += dz[i * C + c];
+            worst = fmax(worst, fabs(rs));
+            if (i == 1 && (dz[C] != 0.f || dz[C + 1] != 0.f || dz[C + 2] != 0.f)) { fprintf(stderr, "gradient of a row outside the mask is not zero\n"); return 9; }
+        }
+    }
     /* error channel: a hop mask beyond the plan must fail cleanly */
     int st = h2gcn_spmm_hops_f32(plan, 0x8, dx, D, D, dy, H * D, D, NULL);
     h2gcn_plan_destroy(plan);
