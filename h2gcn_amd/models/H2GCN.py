@@ -80,17 +80,12 @@ def _is_sharded() -> bool:
 
 def make_optimizer(name: str, params, lr: float, capturable: bool = False):
     name = name.lower()
-    if name == "adam":  # keras defaults: beta 0.9 / 0.999, epsilon 1e-7
-        params = list(params)
-        kw = dict(lr=lr, betas=(0.9, 0.999), eps=1e-7, capturable=capturable)
-        if params and all(p.is_cuda for p in params):
-            # one multi-tensor kernel per step instead of ~10 (39 vs 141 us eager, 46 vs 99 us inside a replayed hipGraph, for
-            # H2GCN-2's four parameters): small graphs are launch-bound
-            try:
-                return torch.optim.Adam(params, fused=True, **kw)
-            except (RuntimeError, TypeError, ValueError):
-                pass
-        return torch.optim.Adam(params, **kw)
+    if name == "adam":
+        # Keras Adam with its defaults (beta 0.9 / 0.999, epsilon 1e-7) and Keras' placement of epsilon -- on the uncorrected
+        # sqrt(v), not torch's bias-corrected one -- as ONE kernel launch per step for all parameters (`h2gcn_amd/optim.py`;
+        # stock multi-tensor Adam: ~10 launches, 141 us eager / 99 us replayed for H2GCN-2's four tensors); always capturable
+        from ..optim import KerasAdam
+        return KerasAdam(params, lr=lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7)
     if name == "sgd":
         return torch.optim.SGD(params, lr=lr)
     if name == "rmsprop":

@@ -1,0 +1,75 @@
+"""The reference's optimizer step on the library's one-launch kernel (``csrc/optimizer.hip``).
+
+Reference: ``keras.optimizers.get(optimizer).from_config({"lr": lr})`` + ``optimizer.apply_gradients``
+(``h2gcn/models/H2GCN.py:62-63, 73``), i.e. Keras Adam with its defaults (beta_1 0.9, beta_2 0.999, epsilon 1e-7).  Keras /
+TensorFlow add epsilon to the UNCORRECTED ``sqrt(v)``::
+
+    alpha = lr * sqrt(1 - beta_2**t) / (1 - beta_1**t)
+    m += (g - m) * (1 - beta_1);  v += (g*g - v) * (1 - beta_2);  param -= (m * alpha) / (sqrt(v) + epsilon)
+
+whereas ``torch.optim.Adam`` adds it to the bias-corrected one -- the same update only when epsilon is negligible.  This class
+keeps the reference's form.  GPU fp32 parameters: ONE kernel launch per step for all tensors, the step counter in device memory
+(bumped by a stream-ordered op, so the step is capturable into a hipGraph).  Other parameters (CPU tensors in the CPU test
+suite): the same formula as torch expressions.
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+
+
+class KerasAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 0.001, beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-7):
+        if lr < 0 or not 0 <= beta_1 < 1 or not 0 <= beta_2 < 1 or epsilon < 0:
+            raise ValueError(f"KerasAdam: lr {lr}, beta_1 {beta_1}, beta_2 {beta_2}, epsilon {epsilon}")
+        super().__init__(params, dict(lr=lr, beta_1=beta_1, beta_2=beta_2, epsilon=epsilon))
+
+    def _state(self, p):
+        st = self.state[p]
+        if not st:
+            st["m"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["v"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            lr, b1, b2, eps = group["lr"], group["beta_1"], group["beta_2"], group["epsilon"]
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            # one step counter per group, on the device of its first parameter (host copy for the CPU formula)
+            if "step_dev" not in group:
+                group["step_dev"] = torch.zeros(1, dtype=torch.int64, device=ps[0].device)
+                group["step_host"] = 0
+            group["step_dev"] += 1
+            group["step_host"] += 1
+            fast = [p for p in ps if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.device == group["step_dev"].device]
+            slow = [p for p in ps if not any(p is q for q in fast)]
+            if fast:
+                grads = [p.grad if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else p.grad.to(torch.float32).contiguous() for p in fast]
+                states = [self._state(p) for p in fast]
+                n = len(fast)
+                arr = C.c_void_p * n
+                with torch.cuda.device(fast[0].device):
+                    stream = torch.cuda.current_stream(fast[0].device).cuda_stream
+                    _capi.check(_capi.lib().h2gcn_adam_keras_f32(
+                        n, arr(*[p.data_ptr() for p in fast]), arr(*[g.data_ptr() for g in grads]),
+                        arr(*[s["m"].data_ptr() for s in states]), arr(*[s["v"].data_ptr() for s in states]),
+                        (C.c_int64 * n)(*[p.numel() for p in fast]), lr, b1, b2, eps,
+                        C.c_void_p(group["step_dev"].data_ptr()), 0, C.c_void_p(stream)))
+            for p in slow:
+                st = self._state(p)
+                t = group["step_host"]
+                one, tb1, tb2 = (torch.tensor(x, dtype=torch.float32) for x in (1.0, b1, b2))   # fp32 like the kernel
+                alpha = (torch.tensor(lr, dtype=torch.float32) * torch.sqrt(one - tb2 ** t) / (one - tb1 ** t)).item()
+                g = p.grad
+                st["m"].add_((g - st["m"]) * (one - tb1).item())
+                st["v"].add_((g * g - st["v"]) * (one - tb2).item())
+                p.sub_((st["m"] * alpha) / (st["v"].sqrt() + eps))
+        return loss

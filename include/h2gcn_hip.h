@@ -370,6 +370,21 @@ int h2gcn_masked_ce_backward_f32(const float* Z_dev, int64_t ldz, int64_t n_rows
                                  const float* w_dev, const float* gscale_dev, float* dZ_dev, int64_t lddz, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * The reference's optimizer step: Keras Adam as `optimizer.apply_gradients` runs it (reference h2gcn/models/H2GCN.py:62-63, 73;
+ * TensorFlow's ApplyAdam, a third-party kernel absent from the reference tree), for ALL parameter tensors in one launch:
+ *     alpha = lr * sqrt(1 - beta_2^t) / (1 - beta_1^t)                          t = 1-based step, all arithmetic fp32
+ *     m += (g - m) * (1 - beta_1);  v += (g*g - v) * (1 - beta_2);  param -= (m * alpha) / (sqrt(v) + epsilon)
+ * (epsilon joins the UNCORRECTED sqrt(v): Keras / TensorFlow semantics, not torch.optim.Adam's).  params / grads / m / v / sizes
+ * are HOST arrays of n_tensors device pointers / element counts (contiguous fp32 tensors; m and v zero before step 1).
+ * t is read from *step_dev when step_dev != NULL (device memory: the caller bumps it with a stream-ordered op, so a captured
+ * hipGraph advances it on every replay), else from `step`.
+ */
+#define H2GCN_ADAM_MAX_TENSORS 16   /* tensors per launch; longer lists are processed in groups */
+int h2gcn_adam_keras_f32(int32_t n_tensors, float* const* params_dev, const float* const* grads_dev, float* const* m_dev,
+                         float* const* v_dev, const int64_t* sizes, float lr, float beta1, float beta2, float epsilon,
+                         const int64_t* step_dev, int64_t step, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Row-shard exchange between the GPUs of one node (no counterpart in the reference: it is single-process,
  * single-device -- SURVEY.md 8(e) adds the row partition).  Before a hop aggregation every rank needs the whole
  * embedding X[N, d] while it owns only X[rows_p, :]; this object performs that all-gather WITHOUT a collective

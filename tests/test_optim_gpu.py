@@ -1,0 +1,100 @@
+"""GPU suite: the one-launch Adam kernel with the reference's (Keras / TensorFlow) arithmetic (csrc/optimizer.hip) against its
+fp32 restatement (oracle/keras_adam.py).  Tolerance 2e-6 relative: the same fp32 operations in the same order; powf / sqrtf of
+the device library may differ from numpy's in the last bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import keras_adam as ok
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _params(shapes, seed):
+    rng = np.random.default_rng(seed)
+    return [rng.normal(size=s).astype(np.float32) for s in shapes]
+
+
+def test_steps_match_the_restatement_over_many_tensors():
+    from h2gcn_amd.optim import KerasAdam
+    shapes = [(1433, 64), (64,), (448, 7), (7,), (1,), (3, 5, 2)] + [(11,)] * 14       # 20 tensors: two launch groups
+    host = _params(shapes, 1)
+    ps = [torch.nn.Parameter(torch.from_numpy(h.copy()).to(DEV)) for h in host]
+    opt = KerasAdam(ps, lr=0.01)
+    m = [np.zeros_like(h) for h in host]
+    v = [np.zeros_like(h) for h in host]
+    rng = np.random.default_rng(2)
+    for t in range(1, 13):
+        gs = [rng.normal(size=h.shape).astype(np.float32) * np.float32(10.0 ** rng.integers(-7, 1)) for h in host]
+        for p, g in zip(ps, gs):
+            p.grad = torch.from_numpy(g).to(DEV)
+        opt.step()
+        for k in range(len(host)):
+            host[k], m[k], v[k] = ok.keras_adam_step(host[k], gs[k], m[k], v[k], t, lr=0.01)
+    for p, h in zip(ps, host):
+        got = p.detach().cpu().numpy()
+        assert np.abs(got - h).max() <= 2e-6 * max(1.0, np.abs(h).max()), np.abs(got - h).max()
+
+
+def test_tiny_gradients_follow_keras_not_torch():
+    """|g| = 1e-6: Keras moves the weight by 0.24 lr at step 1 (epsilon on the uncorrected sqrt(v)), torch.optim.Adam by 0.91 lr."""
+    from h2gcn_amd.optim import KerasAdam
+    w = torch.nn.Parameter(torch.zeros(4, device=DEV))
+    w.grad = torch.full((4,), 1e-6, device=DEV)
+    KerasAdam([w], lr=0.01).step()
+    assert abs(w[0].item() / -0.01 - 0.2403) < 2e-3
+    w2 = torch.nn.Parameter(torch.zeros(4, device=DEV))
+    w2.grad = torch.full((4,), 1e-6, device=DEV)
+    torch.optim.Adam([w2], lr=0.01, eps=1e-7).step()
+    assert abs(w2[0].item() / -0.01 - 0.909) < 5e-3
+
+
+def test_replayed_graph_advances_the_step_counter():
+    from h2gcn_amd.optim import KerasAdam
+    host = _params([(100, 8), (8,)], 3)
+    g_host = _params([(100, 8), (8,)], 4)
+
+    def run(graph):
+        ps = [torch.nn.Parameter(torch.from_numpy(h.copy()).to(DEV)) for h in host]
+        for p, g in zip(ps, g_host):
+            p.grad = torch.from_numpy(g).to(DEV)
+        opt = KerasAdam(ps, lr=0.05)
+        if not graph:
+            for _ in range(5):
+                opt.step()
+        else:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                opt.step()                                   # warm-up step 1 (allocates the state)
+            torch.cuda.current_stream().wait_stream(side)
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                opt.step()                                   # captured, not executed: step 2 happens on the first replay ...
+            # ... except that the host-side bump inside the capture also ran its `+= 1` node once per replay only
+            for _ in range(4):
+                cg.replay()
+        torch.cuda.synchronize()
+        return [p.detach().cpu().numpy() for p in ps], int(opt.param_groups[0]["step_dev"].item())
+
+    eager, t_e = run(False)
+    replay, t_r = run(True)
+    assert t_e == 5 and t_r == 5
+    for a, b in zip(eager, replay):
+        assert np.array_equal(a, b)
+
+
+def test_capi_rejects_bad_arguments():
+    from h2gcn_amd import _capi
+    L = _capi.lib()
+    x = torch.zeros(8, device=DEV)
+    arr = (C.c_void_p * 1)(x.data_ptr())
+    n = (C.c_int64 * 1)(8)
+    call = lambda lr, b1, step: L.h2gcn_adam_keras_f32(1, arr, arr, arr, arr, n, lr, b1, 0.999, 1e-7, None, step, None)
+    assert call(0.01, 1.0, 1) == _capi.ERR_INVALID_ARGUMENT and b"beta_1" in L.h2gcn_last_error()
+    assert call(0.01, 0.9, 0) == _capi.ERR_INVALID_ARGUMENT and b"1-based" in L.h2gcn_last_error()
+    assert call(-1.0, 0.9, 1) == _capi.ERR_INVALID_ARGUMENT
+    assert L.h2gcn_adam_keras_f32(0, None, None, None, None, None, 0.01, 0.9, 0.999, 1e-7, None, 1, None) == 0

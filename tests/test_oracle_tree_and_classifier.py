@@ -101,3 +101,32 @@ def test_dropout_dense_gradients_by_finite_differences():
     assert np.allclose(db, g.sum(0))
     m = oc.keep_mask(n, k, keep, seed, step)
     assert np.array_equal(dx == 0, ~m)
+
+
+def test_keras_adam_restatement_first_step_by_hand_and_cpu_optimizer_follows_it():
+    """Keras / TensorFlow Adam (reference `H2GCN.py:62-63, 73`): epsilon joins the UNCORRECTED sqrt(v).  First step by hand:
+    m = 0.1 g, v = 0.001 g^2, alpha = lr sqrt(0.001) / 0.1, update = alpha m / (sqrt(v) + eps) = lr g / (|g| + eps / sqrt(0.001))
+    -- so a gradient of 1e-6 moves a weight by lr * 1e-6 / (1e-6 + 3.16e-6) = 0.24 lr, where torch's Adam (epsilon on the
+    corrected sqrt(v)) would move it by lr * 1e-6 / (1e-6 + 1e-7) = 0.91 lr."""
+    import torch
+    from oracle import keras_adam as ok
+    from h2gcn_amd.optim import KerasAdam
+
+    g = np.array([1.0, -2.0, 1e-6, 0.0], np.float32)
+    p, m, v = ok.keras_adam_step(np.zeros(4, np.float32), g, np.zeros(4), np.zeros(4), 1, lr=0.01)
+    want = -0.01 * g.astype(np.float64) / (np.abs(g.astype(np.float64)) + 1e-7 / np.sqrt(0.001))
+    assert np.allclose(p, want, rtol=2e-4, atol=1e-9) and abs(p[2] / -0.01 - 0.2403) < 2e-3 and p[3] == 0
+    assert np.allclose(m, 0.1 * g, rtol=1e-6) and np.allclose(v, 0.001 * g * g, rtol=3e-5)   # fp32(1) - fp32(0.999) = 0.99998713e-3
+    # the CPU branch of the optimizer is the same arithmetic, step after step
+    rng = np.random.default_rng(0)
+    w0 = rng.normal(size=(5, 3)).astype(np.float32)
+    w = torch.nn.Parameter(torch.from_numpy(w0.copy()))
+    opt = KerasAdam([w], lr=0.01)
+    p, m, v = w0.copy(), np.zeros_like(w0), np.zeros_like(w0)
+    for t in range(1, 8):
+        gt = (rng.normal(size=w0.shape) * (10.0 ** rng.integers(-6, 1))).astype(np.float32)
+        w.grad = torch.from_numpy(gt.copy())
+        opt.step()
+        p, m, v = ok.keras_adam_step(p, gt, m, v, t, lr=0.01)
+        assert np.allclose(w.detach().numpy(), p, rtol=2e-6, atol=3e-7), t      # pow / sqrt of torch vs numpy: last-bit differences
+    assert "step_dev" in opt.state_dict()["param_groups"][0]
