@@ -88,8 +88,9 @@ def make_optimizer(name: str, params, lr: float, capturable: bool = False):
         return KerasAdam(params, lr=lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7)
     if name == "sgd":
         return torch.optim.SGD(params, lr=lr)
-    if name == "rmsprop":
-        return torch.optim.RMSprop(params, lr=lr, alpha=0.9, eps=1e-7)
+    if name == "rmsprop":   # Keras / TensorFlow arithmetic (epsilon inside the square root), see optim.KerasRMSprop
+        from ..optim import KerasRMSprop
+        return KerasRMSprop(params, lr=lr, rho=0.9, epsilon=1e-7)
     raise ValueError(f"unsupported optimizer {name!r}")
 
 

@@ -73,3 +73,36 @@ class KerasAdam(torch.optim.Optimizer):
                 st["v"].add_((g * g - st["v"]) * (one - tb2).item())
                 p.sub_((st["m"] * alpha) / (st["v"].sqrt() + eps))
         return loss
+
+
+class KerasRMSprop(torch.optim.Optimizer):
+    """``--optimizer rmsprop``: Keras RMSprop with its defaults (rho 0.9, momentum 0, epsilon 1e-7, not centered) as
+    TensorFlow's ApplyRMSProp computes it -- epsilon INSIDE the square root::
+
+        ms += (g*g - ms) * (1 - rho);   param -= lr * g / sqrt(ms + epsilon)
+
+    (``torch.optim.RMSprop`` divides by ``sqrt(ms) + eps``: with eps = 1e-7 that is a 3e-4 vs 1e-7 floor on the denominator.)
+    Not a hot path (the reference's default is adam): plain torch expressions on any device."""
+
+    def __init__(self, params, lr: float = 0.001, rho: float = 0.9, epsilon: float = 1e-7):
+        if lr < 0 or not 0 <= rho < 1 or epsilon < 0:
+            raise ValueError(f"KerasRMSprop: lr {lr}, rho {rho}, epsilon {epsilon}")
+        super().__init__(params, dict(lr=lr, rho=rho, epsilon=epsilon))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["ms"] = torch.zeros_like(p)
+                g = p.grad
+                st["ms"].add_((g * g - st["ms"]) * (1 - group["rho"]))
+                p.sub_(group["lr"] * g / torch.sqrt(st["ms"] + group["epsilon"]))
+        return loss

@@ -130,3 +130,15 @@ def test_keras_adam_restatement_first_step_by_hand_and_cpu_optimizer_follows_it(
         p, m, v = ok.keras_adam_step(p, gt, m, v, t, lr=0.01)
         assert np.allclose(w.detach().numpy(), p, rtol=2e-6, atol=3e-7), t      # pow / sqrt of torch vs numpy: last-bit differences
     assert "step_dev" in opt.state_dict()["param_groups"][0]
+
+
+def test_keras_rmsprop_by_hand():
+    """TensorFlow's ApplyRMSProp puts epsilon inside the square root: first step ms = 0.1 g^2, update = lr g / sqrt(0.1 g^2 + eps)."""
+    import torch
+    from h2gcn_amd.optim import KerasRMSprop
+    g = np.array([1.0, -0.5, 1e-5, 0.0])
+    w = torch.nn.Parameter(torch.zeros(4, dtype=torch.float64))
+    w.grad = torch.from_numpy(g.copy())
+    KerasRMSprop([w], lr=0.01).step()
+    assert np.allclose(w.detach().numpy(), -0.01 * g / np.sqrt(0.1 * g * g + 1e-7), rtol=1e-12)
+    assert abs(w[2].item() / -0.01 - 1e-5 / np.sqrt(1e-11 + 1e-7)) < 1e-9        # 0.0316: the epsilon floor, not 1 / sqrt(0.1) = 3.16
