@@ -219,7 +219,10 @@ class _FusedPropagation(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, r0: torch.Tensor, plan: HopPlan, rounds: int):
+    def forward(ctx, r0: torch.Tensor, plan: HopPlan, rounds: int, out: Optional[torch.Tensor] = None, reuse: bool = False):
+        """``out``: a caller-owned ``[N, W]`` contiguous buffer to fill instead of a fresh one.  ``reuse``: ``out`` ALREADY
+        holds the propagation of this very ``r0`` (see :func:`fused_propagation`) -- nothing is computed, the buffer only
+        enters the autograd graph (the backward needs none of the forward's values: the rounds are linear)."""
         n, w0 = r0.shape
         H = plan.n_hops
         widths = [w0 * H ** k for k in range(rounds + 1)]
@@ -231,12 +234,18 @@ class _FusedPropagation(torch.autograd.Function):
         for k in range(rounds):
             off[k] = pos
             pos += widths[k]
-        buf = concat_buffer(n, total, r0.device)
-        buf[:, off[0]:off[0] + w0].copy_(r0)
-        for k in range(1, rounds + 1):
-            src = buf[:, off[k - 1]:off[k - 1] + widths[k - 1]]
-            dst = buf[:, off[k]:off[k] + widths[k]].unflatten(1, (H, widths[k - 1]))
-            plan.spmm(src, out=dst)
+        if out is None:
+            buf = concat_buffer(n, total, r0.device)
+        else:
+            if out.shape != (n, total) or out.dtype != torch.float32 or out.device != r0.device or not out.is_contiguous():
+                raise ValueError(f"fused_propagation: out must be a contiguous float32 [{n}, {total}] tensor on {r0.device}")
+            buf = out.view(n, total)   # a new tensor object on the caller's storage: autograd marks IT as this node's output
+        if not reuse:
+            buf[:, off[0]:off[0] + w0].copy_(r0)
+            for k in range(1, rounds + 1):
+                src = buf[:, off[k - 1]:off[k - 1] + widths[k - 1]]
+                dst = buf[:, off[k]:off[k] + widths[k]].unflatten(1, (H, widths[k - 1]))
+                plan.spmm(src, out=dst)
         ctx.plan, ctx.rounds, ctx.widths, ctx.off = plan, rounds, widths, off
         return buf
 
@@ -259,7 +268,7 @@ class _FusedPropagation(torch.autograd.Function):
                 g_prev = plan.spmm_t(g_k.unflatten(1, (H, widths[k - 1])))
                 g_prev += slot
                 g_k = g_prev
-        return g_k, None, None
+        return g_k, None, None, None, None
 
 
 def concat_buffer(n_rows: int, width: int, device) -> torch.Tensor:
@@ -271,15 +280,25 @@ def concat_buffer(n_rows: int, width: int, device) -> torch.Tensor:
     return torch.empty((n_rows, width), dtype=torch.float32, device=device)
 
 
-def fused_propagation(plan: HopPlan, r0: torch.Tensor, rounds: int) -> torch.Tensor:
-    """``[r_K | r_0 | ... | r_{K-1}]`` for ``rounds = K`` aggregation rounds, without intermediate copies."""
+def fused_propagation(plan: HopPlan, r0: torch.Tensor, rounds: int, out: Optional[torch.Tensor] = None,
+                      reuse: bool = False) -> torch.Tensor:
+    """``[r_K | r_0 | ... | r_{K-1}]`` for ``rounds = K`` aggregation rounds, without intermediate copies.
+
+    ``out`` / ``reuse``: the propagation is a deterministic function of ``(plan, r0)``, and an epoch of the reference evaluates
+    the model right after every update (``run_experiments.py:44-61``: ``train_step`` then ``test_step``) -- so the next
+    epoch's training forward recomputes exactly the buffer the evaluation has just produced whenever nothing stochastic
+    precedes the propagation (H2GCN's default setup: the only dropout sits behind it).  A caller that knows this
+    (``models.H2GCN``) lets the evaluation fill a persistent buffer (``out=``) and hands the same buffer to the training
+    forward with ``reuse=True``: same bits, one propagation per epoch instead of two."""
     if rounds < 1:
         raise ValueError("rounds must be >= 1")
     if r0.dim() != 2 or r0.shape[0] != plan.n_cols or plan.n_rows != plan.n_cols:
         raise ValueError(f"r0 must be [{plan.n_cols}, d] and the hop matrices square")
+    if reuse and out is None:
+        raise ValueError("fused_propagation: reuse=True needs the buffer that holds the propagation (out=)")
     if r0.requires_grad and torch.is_grad_enabled():
-        return _FusedPropagation.apply(r0, plan, rounds)
-    return _FusedPropagation.forward(_NoCtx(), r0, plan, rounds)
+        return _FusedPropagation.apply(r0, plan, rounds, out, reuse)
+    return _FusedPropagation.forward(_NoCtx(), r0, plan, rounds, out, reuse)
 
 
 class _NoCtx:

@@ -10,6 +10,7 @@ checkpoint per epoch; signac bookkeeping and the attention / experimental layer 
 """
 from __future__ import annotations
 
+import functools
 import operator
 import os
 
@@ -39,6 +40,9 @@ def add_subparser_args(parser):
     g.add_argument("--no_feature_normalize", action="store_true")
     g.add_argument("--adj_norm", choices=["sym", "rw"], default="sym",
                    help="hop normalisation: sym = D^-1/2 A D^-1/2 (reference default), rw = D^-1 A")
+    g.add_argument("--no_propagation_reuse", action="store_true",
+                   help="recompute the propagation in every training forward instead of adopting the buffer the preceding "
+                        "evaluation produced (same results either way; see H2GCN.reuse_propagation)")
     g.add_argument("--no_fused_classifier", action="store_true",
                    help="run `D<rate>` followed by a dense layer as the stock dropout + matmul pair instead of the library's "
                         "one-pass dropout+Dense kernels (csrc/classifier.hip)")
@@ -103,7 +107,8 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
                   n_hops=(tensors["adj_hops"].n_hops if tensors["adj_hops"] is not None else 0),
                   sparse_input=not dense_features, l2_regularize_weight=l2_regularize_weight,
                   sparse_dropout_at_eval=getattr(args, "sparse_dropout_at_eval", False),
-                  fused_classifier=not getattr(args, "no_fused_classifier", False)).to(device)
+                  fused_classifier=not getattr(args, "no_fused_classifier", False),
+                  reuse_propagation=not getattr(args, "no_propagation_reuse", False)).to(device)
     sharded = _is_sharded()
     if sharded:  # replicas must start identical whatever the seeding on each rank (e.g. --random_seed 0)
         for p_ in model.parameters():
@@ -131,6 +136,7 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
         train_loss.backward()
         model.restore_sparse_inputs()   # SparseDropout pointed the shared feature operand at dropped values
         optimizer.step()
+        model.note_update()
         return dict(train_loss=train_loss.detach())
 
     # The three masked accuracies and two masked losses of an evaluation (reference ``test_step``, ``:77-107``) share
@@ -182,7 +188,8 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
         train_step, test_step = _sharded_steps(model, optimizer)
     if use_graphs:
         train_step, test_step = _GraphedSteps(train_step, test_step, optimizer, device,
-                                              prepare=getattr(hops_obj, "prepare_capture", None) if sharded else None).wrap()
+                                              prepare=getattr(hops_obj, "prepare_capture", None) if sharded else None,
+                                              refresh_eval=model.reuse_propagation).wrap()
 
     stats_printer = logger.EpochStatsPrinter()
     args.objects["statsPrinter"] = stats_printer
@@ -330,6 +337,7 @@ def _sharded_steps(model, optimizer):
             p.grad.copy_(total[pos:pos + p.numel()].view_as(p.grad))
             pos += p.numel()
         optimizer.step()
+        model.note_update()
         return dict(train_loss=total[pos] + reg.detach())
 
     @torch.no_grad()
@@ -363,9 +371,12 @@ class _GraphedSteps:
 
     WARMUP = 3
 
-    def __init__(self, train_step, test_step, optimizer, device, prepare=None):
+    def __init__(self, train_step, test_step, optimizer, device, prepare=None, refresh_eval=False):
         self.eager_train, self.eager_test = train_step, test_step
         self.optimizer, self.device = optimizer, device
+        # the captured training step may ADOPT the propagation the evaluation left behind (H2GCN.reuse_propagation): a
+        # training replay that does not follow an evaluation replays the evaluation first, so that what it adopts is current
+        self.refresh_eval, self.eval_is_current = bool(refresh_eval), False
         self.prepare = prepare   # called (device idle) right before each capture: row-partitioned runs reset the
                                  # exchange objects' cross-step event dependencies there
         self.calls = 0
@@ -395,6 +406,7 @@ class _GraphedSteps:
         if self.prepare is not None:
             self.prepare()
         self.train_graph, self.test_graph, self.train_out, self.test_out = g_train, g_test, train_out, test_out
+        self.eval_is_current = True   # the eager evaluation above ran after the eager update
         return eager_out
 
     def wrap(self):
@@ -413,13 +425,17 @@ class _GraphedSteps:
                     self.pending_eager_out = None
                     # the eager pass inside _capture already applied this epoch's update: do not step twice
                     return done if done is not None else self.eager_train(**tensors)
+            if self.refresh_eval and not self.eval_is_current:
+                self.test_graph.replay()
             self.train_graph.replay()
+            self.eval_is_current = False
             return dict(self.train_out)
 
         def test_step(**tensors):
             if self.failed or self.test_graph is None:
                 return self.eager_test(**tensors)
             self.test_graph.replay()
+            self.eval_is_current = True
             return dict(self.test_out)
 
         return train_step, test_step
@@ -458,7 +474,8 @@ class H2GCN(torch.nn.Module):
     concats (``:339-341``).  Feature widths are tracked statically (keras builds lazily)."""
 
     def __init__(self, layer_setups, input_dim: int, n_hops: int = 2, sparse_input: bool = True,
-                 l2_regularize_weight: float = 0.0, sparse_dropout_at_eval: bool = False, fused_classifier: bool = True):
+                 l2_regularize_weight: float = 0.0, sparse_dropout_at_eval: bool = False, fused_classifier: bool = True,
+                 reuse_propagation: bool = True):
         super().__init__()
         self.l2 = float(l2_regularize_weight)
         self.layer_objs = torch.nn.ModuleList()
@@ -547,6 +564,39 @@ class H2GCN(torch.nn.Module):
                 tag_width[tag] = width
         self.output_width = width
         self.fused = self._find_fusable_block(layer_setups, n_hops)
+        # Propagation reuse (see layers.fused_propagation): an epoch is train_step then test_step, so the training forward
+        # of epoch e+1 recomputes exactly what the evaluation of epoch e has just produced -- provided every layer in front of
+        # the propagation behaves the same in both modes (no dropout there; H2GCN's default `M64-R-T1-G-V-...-D0.5-MO` has its
+        # only dropout behind the concat).  The evaluation then fills a persistent buffer and the next training forward
+        # adopts it: one propagation per epoch instead of two, same bits.
+        self.reuse_propagation = (bool(reuse_propagation) and self.fused is not None
+                                  and os.environ.get("H2GCN_PROPAGATION_REUSE", "1") != "0"
+                                  and all(self._same_in_both_modes(m) for m in list(self.layer_objs)[: self.fused[0]]))
+        self._weights_tag = 0        # bumped whenever the parameters change (note_update)
+        self._prop_key = None        # what the persistent buffer currently holds
+        self._prop_buf = None
+
+    @staticmethod
+    def _same_in_both_modes(layer) -> bool:
+        if isinstance(layer, (torch.nn.Dropout, L.SparseDropout)):
+            return False
+        if isinstance(layer, L.DropoutDense):
+            return layer.drop_prob == 0.0
+        return True
+
+    def note_update(self) -> None:
+        """The parameters have changed (optimizer step, restored snapshot): what the propagation buffer holds is stale."""
+        self._weights_tag += 1
+
+    def load_state_dict(self, *args, **kwargs):
+        self.note_update()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _propagation_buffer(self, n: int, width: int, device) -> torch.Tensor:
+        b = self._prop_buf
+        if b is None or b.shape != (n, width) or b.device != device:
+            self._prop_buf, self._prop_key = L.concat_buffer(n, width, device), None
+        return self._prop_buf
 
     @staticmethod
     def _find_fusable_block(layer_setups, n_hops):
@@ -585,6 +635,7 @@ class H2GCN(torch.nn.Module):
             execute_after = n_layers + execute_after
         tagged = {}
         skip_until = 0
+        feat_key = (id(inputs), execute_after)   # which feature operand this pass started from
         for ind, layer in enumerate(self.layer_objs):
             if ind == return_before:
                 return inputs
@@ -595,10 +646,25 @@ class H2GCN(torch.nn.Module):
                 # concat-free propagation: layers fused[0] .. fused[1]-1 in one go (row-sharded runs: the shard's
                 # rows of the same buffer, one exchange per round)
                 _, end, K, tags = self.fused
-                if hasattr(adjhops, "fused_propagation"):
-                    inputs = adjhops.fused_propagation(inputs, K)
+                sharded_hops = hasattr(adjhops, "fused_propagation")
+                propagate = adjhops.fused_propagation if sharded_hops else functools.partial(L.fused_propagation, adjhops)
+                if self.reuse_propagation and inputs.is_cuda:
+                    # (row-partitioned runs: every rank takes the same branch -- the decision depends only on the call
+                    # sequence, which is the same on all ranks)
+                    H_ = adjhops.n_hops
+                    width = inputs.shape[1] * sum(H_ ** k for k in range(K + 1))
+                    buf = self._propagation_buffer(inputs.shape[0], width, inputs.device)
+                    key = (self._weights_tag, id(adjhops), feat_key, tuple(inputs.shape), K)
+                    if not torch.is_grad_enabled():          # evaluation: fill the persistent buffer
+                        self._prop_key = None
+                        inputs = propagate(inputs, K, out=buf)
+                        self._prop_key = key
+                    elif self._prop_key == key:              # training forward right after it: adopt the buffer
+                        inputs = propagate(inputs, K, out=buf, reuse=True)
+                    else:                                    # anything else (first step, two training steps in a row, ...)
+                        inputs = propagate(inputs, K)
                 else:
-                    inputs = L.fused_propagation(adjhops, inputs, K)
+                    inputs = propagate(inputs, K)
                 skip_until = end
                 w0 = tagged[tags[0]].shape[1]
                 H = adjhops.n_hops

@@ -556,7 +556,9 @@ class _ShardedFusedPropagation(torch.autograd.Function):
     the rounds in reverse: shard adjoint, reduce-scatter, add the slot's incoming gradient."""
 
     @staticmethod
-    def forward(ctx, r0, hops_obj, rounds):
+    def forward(ctx, r0, hops_obj, rounds, out=None, reuse=False):
+        """``out`` / ``reuse``: as in :func:`h2gcn_amd.layers.fused_propagation` -- a caller-owned buffer to fill, or (``reuse``)
+        one that already holds the propagation of this ``r0``: no exchange and no SpMM then, on any rank."""
         plan = hops_obj.plan
         n_local, w0 = r0.shape
         H = plan.n_hops
@@ -567,12 +569,19 @@ class _ShardedFusedPropagation(torch.autograd.Function):
             off[k] = pos
             pos += widths[k]
         from .layers import concat_buffer
-        buf = concat_buffer(n_local, sum(widths), r0.device)
-        buf[:, off[0]:off[0] + w0].copy_(r0)
-        for k in range(1, rounds + 1):
-            src = buf[:, off[k - 1]:off[k - 1] + widths[k - 1]]
-            dst = buf[:, off[k]:off[k] + widths[k]].unflatten(1, (H, widths[k - 1]))
-            hops_obj.pipeline(widths[k - 1])(src, out=dst)
+        total = sum(widths)
+        if out is None:
+            buf = concat_buffer(n_local, total, r0.device)
+        else:
+            if out.shape != (n_local, total) or out.dtype != torch.float32 or out.device != r0.device or not out.is_contiguous():
+                raise ValueError(f"fused_propagation: out must be a contiguous float32 [{n_local}, {total}] tensor on {r0.device}")
+            buf = out.view(n_local, total)
+        if not reuse:
+            buf[:, off[0]:off[0] + w0].copy_(r0)
+            for k in range(1, rounds + 1):
+                src = buf[:, off[k - 1]:off[k - 1] + widths[k - 1]]
+                dst = buf[:, off[k]:off[k] + widths[k]].unflatten(1, (H, widths[k - 1]))
+                hops_obj.pipeline(widths[k - 1])(src, out=dst)
         ctx.hops_obj, ctx.rounds, ctx.widths, ctx.off = hops_obj, rounds, widths, off
         return buf
 
@@ -587,7 +596,7 @@ class _ShardedFusedPropagation(torch.autograd.Function):
             g_prev = _reduce_scatter_dx(layer, plan.spmm_t(g_k.unflatten(1, (H, widths[k - 1]))))
             g_prev = g_prev + grad[:, off[k - 1]:off[k - 1] + widths[k - 1]]
             g_k = g_prev
-        return g_k, None, None
+        return g_k, None, None, None, None
 
 
 class ShardedHops:
@@ -686,17 +695,21 @@ class ShardedHops:
                 raise ValueError(f"GCNLayer(hops={sorted(hops)}) selects none of the {self.n_hops} hops")
         return sharded_hop_spmm(self.pipeline(int(x_local.shape[1])), x_local, sel)
 
-    def fused_propagation(self, r0_local: torch.Tensor, rounds: int) -> torch.Tensor:
+    def fused_propagation(self, r0_local: torch.Tensor, rounds: int, out: Optional[torch.Tensor] = None,
+                          reuse: bool = False) -> torch.Tensor:
         """``[r_K | r_0 | ... | r_{K-1}]`` of this rank's rows without intermediate copies (see
-        :class:`_ShardedFusedPropagation`)."""
+        :class:`_ShardedFusedPropagation`); ``out`` / ``reuse`` as in :func:`h2gcn_amd.layers.fused_propagation` (every rank must
+        make the same choice: a reusing rank takes no part in the exchange)."""
         if rounds < 1 or r0_local.dim() != 2 or r0_local.shape[0] != self.n_rows:
             raise ValueError(f"r0 must be [{self.n_rows}, d] and rounds >= 1")
+        if reuse and out is None:
+            raise ValueError("fused_propagation: reuse=True needs the buffer that holds the propagation (out=)")
         if r0_local.requires_grad and torch.is_grad_enabled():
-            return _ShardedFusedPropagation.apply(r0_local, self, rounds)
+            return _ShardedFusedPropagation.apply(r0_local, self, rounds, out, reuse)
 
         class _Ctx:
             pass
-        return _ShardedFusedPropagation.forward(_Ctx(), r0_local, self, rounds)
+        return _ShardedFusedPropagation.forward(_Ctx(), r0_local, self, rounds, out, reuse)
 
 
 def slice_csr_rows(rowptr: torch.Tensor, colidx: torch.Tensor, vals: torch.Tensor, r0: int, r1: int):

@@ -337,3 +337,59 @@ def test_citeseer_forward_matches_oracle_and_trains(tmp_path, capsys):
                                  "--epochs", "60", "--random_seed", "123"])
     best = args.objects["best_val_stats"]
     assert best["val_acc"] >= 0.55 and np.isfinite(args.objects["epoch_stats"]["train_loss"])
+
+
+def _train_epochs(model, tensors, n_epochs, pattern="te"):
+    """`pattern`: what one epoch does -- "te" = training step + evaluation (the reference's loop), "tt" = two training steps
+    in a row before an evaluation.  Returns the parameter values and the logits of the final evaluation."""
+    from h2gcn_amd.models.H2GCN import make_optimizer
+    opt = make_optimizer("adam", model.parameters(), 0.01)
+    args = (tensors["adj"], tensors["features"], tensors["adj_hops"])
+    logits = None
+    for _ in range(n_epochs):
+        for what in pattern:
+            if what == "t":
+                model.train()
+                opt.zero_grad(set_to_none=True)
+                model.loss(model(*args), tensors["y_train"], tensors["train_mask"]).backward()
+                opt.step()
+                model.note_update()
+            else:
+                model.eval()
+                with torch.no_grad():
+                    logits = model(*args)
+    return [p.detach().clone() for p in model.parameters()], logits.clone()
+
+
+@pytest.mark.parametrize("pattern", ["te", "tte", "et"])
+def test_propagation_reuse_is_invisible_in_the_results(tmp_path, monkeypatch, pattern):
+    """The training forward adopts the propagation buffer the evaluation has just filled (one propagation per epoch instead
+    of two).  Same bits as recomputing it -- parameters after 6 epochs and the final logits -- also when the train / evaluate
+    alternation is broken (two training steps in a row: the second one must NOT adopt a stale buffer)."""
+    from h2gcn_amd.models.H2GCN import H2GCN
+
+    results = {}
+    for reuse in ("1", "0"):
+        monkeypatch.setenv("H2GCN_PROPAGATION_REUSE", reuse)
+        g, data, tensors, setup, _ = _setup(tmp_path)
+        torch.manual_seed(0)
+        model = H2GCN(setup, input_dim=tensors["features"].n_cols, n_hops=2, l2_regularize_weight=5e-4).to("cuda:0")
+        assert model.reuse_propagation == (reuse == "1")
+        for layer in model.layer_objs:          # identical dropout streams in both runs
+            if hasattr(layer, "seed"):
+                layer.seed = 1234
+        results[reuse] = _train_epochs(model, tensors, 6, pattern)
+        if reuse == "1" and "te" in pattern * 2:
+            assert model._prop_key is not None
+    for a, b in zip(results["1"][0], results["0"][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(results["1"][1], results["0"][1])
+
+
+def test_propagation_reuse_is_off_when_a_dropout_precedes_the_propagation(tmp_path):
+    g, data, tensors, setup, model = _setup(tmp_path, "D0.5-M64-R-T1-G-V-T2-G-V-C1-C2-D0.5-MO")
+    assert not model.reuse_propagation
+    g, data, tensors, setup, model = _setup(tmp_path, "M64-R-D0.5-T1-G-V-T2-G-V-C1-C2-MO")
+    assert not model.reuse_propagation
+    g, data, tensors, setup, model = _setup(tmp_path)
+    assert model.reuse_propagation

@@ -158,6 +158,36 @@ if int(os.environ.get("RANK", "0")) == 0:
     json.dump(stats, open(os.environ["OUT_FILE"], "w"))
 '''
 
+def test_row_partitioned_propagation_reuse_is_invisible(tmp_path):
+    """2 ranks: the training forward adopts the propagation the preceding evaluation left in the rank's persistent buffer (no
+    exchange, no SpMM in that forward, on either rank).  Final statistics are identical -- to the last bit of the printed floats
+    -- with `--no_propagation_reuse`."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import load_planetoid_golden
+    from test_entrypoints import _export_fixture
+
+    data_dir = tmp_path / "data"
+    _export_fixture(load_planetoid_golden("cora"), data_dir, "ind.cora")
+    results = {}
+    for extra in ("", "--no_propagation_reuse"):
+        port = _free_port()
+        out_file = tmp_path / f"stats_{len(extra)}.json"
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, H2GCN_ROOT=str(ROOT), DATA_DIR=str(data_dir), OUT_FILE=str(out_file), EPOCHS="8", EXTRA=extra,
+                       NETWORK="M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", H2GCN_EXCHANGE="ipc_engine", RANK=str(rank), LOCAL_RANK=str(rank),
+                       WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1")
+            procs.append(subprocess.Popen([sys.executable, "-c", TRAIN_WORKER_TIMED], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        results[extra] = json.loads(out_file.read_text())
+    for k in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_accuracy"):
+        assert results[""][k] == results["--no_propagation_reuse"][k], (k, results[""][k], results["--no_propagation_reuse"][k])
+
+
+
+
 
 def test_row_partitioned_training_replays_as_hipgraph(tmp_path):
     """Row-partitioned training with every exchange on the library's copy-kernel IPC path (H2GCN_EXCHANGE=ipc_kernel):
