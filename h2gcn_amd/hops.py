@@ -125,6 +125,7 @@ class HopPlan:
             stream = torch.cuda.current_stream(self.device).cuda_stream
             _capi.check(_capi.lib().h2gcn_plan_set_values(self._handle, int(hop), C.c_void_p(vals.data_ptr()), C.c_void_p(stream)))
         self.vals[hop] = vals
+        self.values_version = getattr(self, "values_version", 0) + 1   # anything cached as a function of the values is stale
 
     # ------------------------------------------------------------------ introspection
     @property

@@ -635,7 +635,8 @@ class H2GCN(torch.nn.Module):
             execute_after = n_layers + execute_after
         tagged = {}
         skip_until = 0
-        feat_key = (id(inputs), execute_after)   # which feature operand this pass started from
+        # which feature operand (and which state of it) this pass started from
+        feat_key = (id(inputs), getattr(inputs, "values_version", 0), getattr(inputs, "_version", 0), execute_after)
         for ind, layer in enumerate(self.layer_objs):
             if ind == return_before:
                 return inputs
@@ -654,7 +655,8 @@ class H2GCN(torch.nn.Module):
                     H_ = adjhops.n_hops
                     width = inputs.shape[1] * sum(H_ ** k for k in range(K + 1))
                     buf = self._propagation_buffer(inputs.shape[0], width, inputs.device)
-                    key = (self._weights_tag, id(adjhops), feat_key, tuple(inputs.shape), K)
+                    plan_ = getattr(adjhops, "plan", adjhops)
+                    key = (self._weights_tag, id(adjhops), getattr(plan_, "values_version", 0), feat_key, tuple(inputs.shape), K)
                     if not torch.is_grad_enabled():          # evaluation: fill the persistent buffer
                         self._prop_key = None
                         inputs = propagate(inputs, K, out=buf)
