@@ -13,7 +13,11 @@ C ABI of ``include/h2gcn_hip.h``).  It mirrors the reference's operator interfac
 * :mod:`h2gcn_amd.partition` -- row partitioning (equal or nnz-balanced blocks) + embedding exchange (RCCL all-gather or
   the library's IPC pulls) for 1..8 GPUs (new; the reference is single-device);
 * :class:`h2gcn_amd.layers.DropoutDense` -- keras ``Dropout`` + output ``Dense`` (``D0.5-MO``) as one pass over the concat
-  buffer per direction (reference ``h2gcn/models/H2GCN.py:235-257``).
+  buffer per direction (reference ``h2gcn/models/H2GCN.py:235-257``);
+* :mod:`h2gcn_amd.metrics` -- masked softmax cross-entropy / accuracy in one pass over the logits
+  (reference ``h2gcn/models/_metrics.py:8-25``);
+* :class:`h2gcn_amd.optim.KerasAdam` -- the reference's optimizer step (Keras / TensorFlow Adam arithmetic) as one launch for
+  all parameters (reference ``h2gcn/models/H2GCN.py:62-63, 73``).
 
 Results of the aggregation are bit-reproducible functions of the operands (one canonical summation tree in every kernel):
 any slicing, chunking or row partition gives the same bits.
