@@ -114,13 +114,17 @@ __global__ __launch_bounds__(kThreads) void masked_metrics_kernel(const float* _
         }
         if (!any) continue;   // uniform inside the 16-lane group: the butterflies below only pair lanes of one group
         const f4u z = load_quad(Z + row * ldz, c0, C);
+        f4u ys[kMaxSets];   // every label row this row needs is requested before the first reduction (one memory latency, not two)
+#pragma unroll
+        for (int m = 0; m < kMaxSets; ++m)
+            if (m < s.n && w[m] != 0.f) ys[m] = load_quad(s.y[m] + row * s.ldy[m], c0, C);   // zero beyond C
         float mx, lse;
         row_lse(z, c0, C, mx, lse);
         const int zi = grp_argmax(z, c0, C);
 #pragma unroll
         for (int m = 0; m < kMaxSets; ++m) {
             if (m >= s.n || w[m] == 0.f) continue;
-            const f4u y = load_quad(s.y[m] + row * s.ldy[m], c0, C);   // zero beyond C
+            const f4u y = ys[m];
             const float ydot = grp_sum(y[0] * z[0] + y[1] * z[1] + y[2] * z[2] + y[3] * z[3]);
             const float ysum = grp_sum((y[0] + y[1]) + (y[2] + y[3]));
             const int yi = grp_argmax(y, c0, C);
