@@ -595,7 +595,8 @@ class H2GCN(torch.nn.Module):
     def _propagation_buffer(self, n: int, width: int, device) -> torch.Tensor:
         b = self._prop_buf
         if b is None or b.shape != (n, width) or b.device != device:
-            self._prop_buf, self._prop_key = L.concat_buffer(n, width, device), None
+            with torch.inference_mode(False):   # an ordinary tensor even if the first evaluation runs under inference_mode
+                self._prop_buf, self._prop_key = L.concat_buffer(n, width, device), None
         return self._prop_buf
 
     @staticmethod
