@@ -123,3 +123,56 @@ def test_capi_rejects_bad_arguments():
     assert call(10, 1, 4096) == 0
     assert L.h2gcn_masked_ce_backward_f32(C.c_void_p(z.data_ptr()), 5, 4, 10, C.c_void_p(z.data_ptr()), 70, C.c_void_p(w.data_ptr()), None,
                                           C.c_void_p(z.data_ptr()), 70, None) == _capi.ERR_INVALID_ARGUMENT
+
+
+def test_property_sweep_over_shapes_strides_and_weight_patterns():
+    """hypothesis: class counts 1..64, row counts 1..3000, strided logits / labels, 1..4 sets, sparse / dense / all-zero weight
+    vectors, soft (non one-hot) label rows, logits drawn from a coarse grid (frequent exact ties) -- losses, accuracies and the
+    gradient against the fp64 restatement."""
+    import os
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    from h2gcn_amd import metrics
+
+    @settings(max_examples=int(os.environ.get("H2GCN_FUZZ_EXAMPLES", "150")) // 2, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+    @given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(1, 3000), c=st.integers(1, 64), n_sets=st.integers(1, 4),
+           pad_z=st.integers(0, 5), pad_y=st.integers(0, 3), grid=st.booleans(), soft=st.booleans())
+    def run(seed, n, c, n_sets, pad_z, pad_y, grid, soft):
+        rng = np.random.default_rng(seed)
+        z = rng.integers(-3, 4, (n, c)).astype(np.float32) if grid else rng.normal(0, 3, (n, c)).astype(np.float32)
+        zt = torch.zeros((n, c + pad_z), device=DEV)
+        zt[:, :c] = torch.from_numpy(z).to(DEV)
+        ys, ws, ys_h, ws_h = [], [], [], []
+        for m in range(n_sets):
+            if soft:
+                y = rng.random((n, c)).astype(np.float32) * (rng.random((n, 1)) < 0.8)
+            else:
+                y = np.zeros((n, c), np.float32)
+                y[np.arange(n), rng.integers(0, c, n)] = 1.0
+                y[rng.random(n) < 0.1] = 0.0
+            frac = [0.0, 0.02, 0.5, 1.0][int(rng.integers(0, 4))]
+            mask = rng.random(n) < frac
+            w = (mask / max(1, mask.sum())).astype(np.float32)
+            yt = torch.zeros((n, c + pad_y), device=DEV)
+            yt[:, :c] = torch.from_numpy(y).to(DEV)
+            ys.append(yt[:, :c]); ws.append(torch.from_numpy(w).to(DEV)); ys_h.append(y); ws_h.append(w)
+        loss, acc = metrics.masked_metrics(zt[:, :c], ys, ws)
+        loss, acc = loss.cpu().numpy(), acc.cpu().numpy()
+        z64 = z.astype(np.float64)
+        zs = z64 - z64.max(1, keepdims=True)
+        logp = zs - np.log(np.exp(zs).sum(1, keepdims=True))
+        for m in range(n_sets):
+            y64, w64 = ys_h[m].astype(np.float64), ws_h[m].astype(np.float64)
+            ref_l = float((-(y64 * logp).sum(1) * w64).sum())
+            ref_a = float(((z64.argmax(1) == y64.argmax(1)) * w64).sum())
+            assert abs(loss[m] - ref_l) <= 3e-6 * max(1.0, abs(ref_l)) * max(1.0, float(y64.sum(1).max())), (m, loss[m], ref_l)
+            assert abs(acc[m] - ref_a) <= 2e-6, (m, acc[m], ref_a)
+        # gradient of set 0
+        za = zt[:, :c].detach().requires_grad_(True)
+        metrics.masked_cross_entropy(za, ys[0], ws[0]).backward()
+        p = np.exp(logp)
+        want = ws_h[0].astype(np.float64)[:, None] * (p * ys_h[0].astype(np.float64).sum(1, keepdims=True) - ys_h[0])
+        got = za.grad.cpu().numpy()
+        assert np.abs(got - want).max() <= 3e-6 * max(1e-3, np.abs(want).max()) + 1e-12
+
+    run()

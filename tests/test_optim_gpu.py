@@ -98,3 +98,28 @@ def test_capi_rejects_bad_arguments():
     assert call(0.01, 0.9, 0) == _capi.ERR_INVALID_ARGUMENT and b"1-based" in L.h2gcn_last_error()
     assert call(-1.0, 0.9, 1) == _capi.ERR_INVALID_ARGUMENT
     assert L.h2gcn_adam_keras_f32(0, None, None, None, None, None, 0.01, 0.9, 0.999, 1e-7, None, 1, None) == 0
+
+
+def test_host_step_argument_is_the_device_counter_by_another_route():
+    """step_dev = NULL: the 1-based step comes from the host argument -- same update as with the device counter."""
+    from h2gcn_amd import _capi
+    L = _capi.lib()
+    rng = np.random.default_rng(5)
+    p0, g = rng.normal(size=300).astype(np.float32), rng.normal(size=300).astype(np.float32)
+    outs = []
+    for use_dev in (True, False):
+        p, m, v = (torch.from_numpy(a.copy()).to(DEV) for a in (p0, np.zeros(300, np.float32), np.zeros(300, np.float32)))
+        gt = torch.from_numpy(g).to(DEV)
+        step = torch.zeros(1, dtype=torch.int64, device=DEV)
+        arr = lambda t: (C.c_void_p * 1)(t.data_ptr())
+        for t in range(1, 4):
+            step += 1
+            _capi.check(L.h2gcn_adam_keras_f32(1, arr(p), arr(gt), arr(m), arr(v), (C.c_int64 * 1)(300), 0.01, 0.9, 0.999, 1e-7,
+                                               C.c_void_p(step.data_ptr()) if use_dev else None, t, None))
+        torch.cuda.synchronize()
+        outs.append(p.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    want, m, v = p0.copy(), np.zeros(300, np.float32), np.zeros(300, np.float32)
+    for t in range(1, 4):
+        want, m, v = ok.keras_adam_step(want, g, m, v, t, lr=0.01)
+    assert np.abs(outs[0] - want).max() <= 2e-6 * np.abs(want).max()
