@@ -60,3 +60,10 @@ def test_random_operands_and_schedules(seed, n_rows, n_cols, d, n_hops, mean_deg
     mag_t = sum(abs(h).T.astype(np.float64) @ np.abs(w[:, k, :]).astype(np.float64) for k, h in enumerate(hsel))
     assert (np.abs(dx - want_t) <= 1e-5 * np.maximum(1.0, mag_t)).all()
     assert np.array_equal(dx, og.gcn_layer_grad_tree(hsel, w, n_cols, long_threshold=threshold or 256))
+    # ... and the accumulating adjoint lands exactly `old + sum` in a strided slot of a wider buffer
+    pad = int(rng.integers(0, 4))
+    wide = torch.from_numpy(rng.uniform(-1, 1, (n_cols, d + 2 * pad + 1)).astype(np.float32)).to(dev)
+    before = wide.clone()
+    plan.spmm_t(torch.from_numpy(w).to(dev), hops=sel, out=wide[:, pad:pad + d], accumulate=True)
+    assert torch.equal(wide[:, pad:pad + d], before[:, pad:pad + d] + torch.from_numpy(dx).to(dev))
+    assert torch.equal(wide[:, :pad], before[:, :pad]) and torch.equal(wide[:, pad + d:], before[:, pad + d:])
