@@ -257,9 +257,11 @@ class IpcExchange:
             stream = torch.cuda.current_stream(self.device).cuda_stream
             self._capi.check(self._capi.lib().h2gcn_xchg_allgather_end(self._handle, int(channel), self._C.c_void_p(stream)))
 
-    def reduce_scatter(self, channel: int, src_full: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
-        """Sum over ranks of ``src_full`` ([world * rows_per_rank, w] contiguous), returning this rank's row block
-        ([rows_per_rank, w]); blocks are added in ascending rank order.  The slot must cover the whole matrix."""
+    def reduce_scatter_begin(self, channel: int, src_full: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
+        """Start the sum over ranks of ``src_full`` ([world * rows_per_rank, w] contiguous): stage it, tell the peers, start
+        pulling this rank's row block of every peer (on the library's own streams).  Returns the ``[rows_per_rank, w]``
+        tensor that :meth:`reduce_scatter_end` (same channel) fills -- blocks are added in ascending rank order.  Other work
+        may be issued on the current stream in between: that is the overlap.  The slot must cover the whole matrix."""
         w = int(src_full.shape[1])
         if tuple(src_full.shape) != (self.world * rows_per_rank, w) or not src_full.is_contiguous() or src_full.dtype != torch.float32:
             raise ValueError(f"src must be a contiguous float32 [{self.world * rows_per_rank}, w] matrix")
@@ -269,7 +271,18 @@ class IpcExchange:
             stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             self._capi.check(L.h2gcn_xchg_reduce_scatter_begin(self._handle, int(channel), C.c_void_p(src_full.data_ptr()),
                                                                int(rows_per_rank), w, C.c_void_p(out.data_ptr()), stream))
-            self._capi.check(L.h2gcn_xchg_reduce_scatter_end(self._handle, int(channel), stream))
+        return out
+
+    def reduce_scatter_end(self, channel: int) -> None:
+        C = self._C
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            self._capi.check(self._capi.lib().h2gcn_xchg_reduce_scatter_end(self._handle, int(channel), stream))
+
+    def reduce_scatter(self, channel: int, src_full: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
+        """``reduce_scatter_begin`` + ``reduce_scatter_end``."""
+        out = self.reduce_scatter_begin(channel, src_full, rows_per_rank)
+        self.reduce_scatter_end(channel)
         return out
 
     def check(self) -> None:
@@ -504,23 +517,66 @@ def _reduce_scatter_rows(full: torch.Tensor, per: int, rank: int, group=None) ->
     return out
 
 
-def _reduce_scatter_dx(layer: "PipelinedHopAggregation", dx_full: torch.Tensor) -> torch.Tensor:
-    """Full-height adjoint contribution ``A_k[rows_p, :]^T dY_p`` ([N, d]) -> this rank's rows of the summed gradient."""
+def _adjoint_reduce_scatter(layer: "PipelinedHopAggregation", grad_y: torch.Tensor, hops=None) -> torch.Tensor:
+    """Backward of one row-sharded hop aggregation: ``grad_y`` [n_local, H_sel, d] (any strides, last dim contiguous) -> this
+    rank's rows of ``sum_ranks A_k[rows_p, :]^T grad_y_p`` ([n_local, d]).
+
+    The shard adjoint yields a full-height contribution that has to be summed over the ranks and scattered to the row owners
+    -- the mirror image of the forward all-gather, the same bytes.  Like the forward it is pipelined in the
+    layer's feature-column chunks: the adjoint launch of chunk ``c+1`` (main stream) runs while the reduce-scatter of chunk
+    ``c`` is in flight (RCCL on the communication stream, or the library's IPC pulls on its own streams).  Output columns are
+    independent sums, so the chunking never shows in the adjoint's bits."""
+    plan = layer.plan
     if layer.world == 1:
-        return dx_full
-    if dx_full.shape[0] == layer.world * layer.per and dx_full.is_contiguous():
-        padded = dx_full          # already the padded row space
-    else:
-        padded = torch.zeros((layer.world * layer.per, dx_full.shape[1]), dtype=dx_full.dtype, device=dx_full.device)
-        padded[: dx_full.shape[0]] = dx_full
-    if getattr(layer, "ipc", None) is not None:  # the library's own exchange: pulls + a fixed-order sum, no collective library
+        return plan.spmm_t(grad_y, hops=hops)
+    n_local, per, rows = layer.r1 - layer.r0, layer.per, layer.world * layer.per
+    device = layer.device
+    cols = [slice(o, o + w) for o, w in zip(layer.offsets, layer.widths)]
+    out = torch.empty((n_local, layer.d), dtype=torch.float32, device=device)
+
+    def adjoint_chunk(c):   # [world * per, w_c]: the padded row space of the exchange, rows beyond the plan's columns zero
+        g = grad_y[:, :, cols[c]]
+        dx = plan.spmm_t(g, hops=hops)
+        if dx.shape[0] == rows and dx.is_contiguous():
+            return dx
+        full = torch.zeros((rows, layer.widths[c]), dtype=torch.float32, device=device)
+        full[: dx.shape[0]] = dx
+        return full
+
+    if layer.ipc is not None:   # the library's own exchange: pulls + a fixed-order sum, no collective library
         if getattr(layer, "ipc_rs", None) is None:
-            layer.ipc_rs = IpcExchange(1, layer.world * layer.per * layer.d * 4, layer.device, layer.group, mode=layer.exchange[4:],
+            layer.ipc_rs = IpcExchange(layer.C, rows * max(layer.widths) * 4, device, layer.group, mode=layer.exchange[4:],
                                        timeout_ms=layer.ipc_timeout_ms)
-        mine = layer.ipc_rs.reduce_scatter(0, padded, layer.per)
-    else:
-        mine = _reduce_scatter_rows(padded, layer.per, layer.rank, layer.group)
-    return mine[: layer.r1 - layer.r0]
+        pending = []
+        for c in range(layer.C):
+            full = adjoint_chunk(c)
+            pending.append((full, layer.ipc_rs.reduce_scatter_begin(c, full, per)))
+        for c, (full, mine) in enumerate(pending):
+            layer.ipc_rs.reduce_scatter_end(c)
+            out[:, cols[c]] = mine[:n_local]
+        return out
+    if not layer.use_streams:   # CPU / gloo (tests): same schedule, no streams
+        for c in range(layer.C):
+            out[:, cols[c]] = _reduce_scatter_rows(adjoint_chunk(c), per, layer.rank, layer.group)[:n_local]
+        return out
+    main = torch.cuda.current_stream(device)
+    pending = []
+    for c in range(layer.C):
+        full = adjoint_chunk(c)
+        produced = torch.cuda.Event()
+        produced.record(main)
+        with torch.cuda.stream(layer.comm_stream):
+            layer.comm_stream.wait_event(produced)
+            mine = _reduce_scatter_rows(full, per, layer.rank, layer.group)
+            reduced = torch.cuda.Event()
+            reduced.record(layer.comm_stream)
+        full.record_stream(layer.comm_stream)   # allocated on the main stream, consumed on the communication stream
+        mine.record_stream(main)                # and the other way round
+        pending.append((mine, reduced))
+    for c, (mine, reduced) in enumerate(pending):
+        main.wait_event(reduced)
+        out[:, cols[c]] = mine[:n_local]
+    return out
 
 
 class _ShardedHopSpMM(torch.autograd.Function):
@@ -536,9 +592,7 @@ class _ShardedHopSpMM(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_y):
-        layer = ctx.layer
-        dx_full = layer.plan.spmm_t(grad_y.contiguous(), hops=ctx.hops)  # [N, d]
-        return _reduce_scatter_dx(layer, dx_full), None, None
+        return _adjoint_reduce_scatter(ctx.layer, grad_y, ctx.hops), None, None
 
 
 def sharded_hop_spmm(layer: "PipelinedHopAggregation", x_local: torch.Tensor, hops=None) -> torch.Tensor:
@@ -593,7 +647,7 @@ class _ShardedFusedPropagation(torch.autograd.Function):
         g_k = grad[:, off[K]:off[K] + widths[K]]
         for k in range(K, 0, -1):
             layer = hops_obj.pipeline(widths[k - 1])
-            g_prev = _reduce_scatter_dx(layer, plan.spmm_t(g_k.unflatten(1, (H, widths[k - 1]))))
+            g_prev = _adjoint_reduce_scatter(layer, g_k.unflatten(1, (H, widths[k - 1])))
             g_prev = g_prev + grad[:, off[k - 1]:off[k - 1] + widths[k - 1]]
             g_k = g_prev
         return g_k, None, None, None, None
