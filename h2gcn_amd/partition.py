@@ -421,6 +421,34 @@ class PipelinedHopAggregation:
             for c in range(self.C):
                 self._gather(self.full[c], self.send[c], self.group)
 
+    # ---- chunk-level schedule (world > 1): what __call__ does, one chunk at a time, so that a caller can start the exchange
+    #      of a chunk the moment its columns exist (cross-round pipelining in _ShardedFusedPropagation) ----
+    def start_chunk(self, c: int, x_chunk: torch.Tensor) -> None:
+        """Stage this rank's rows of chunk ``c`` (``[n_local, widths[c]]``, any row stride) and start its exchange."""
+        n_local = self.r1 - self.r0
+        if self.ipc is not None:
+            self.ipc.begin(c, x_chunk, self.full[c], self.per, pull=False)
+            self.ipc.pull(c, self.full[c], self.per)
+        elif not self.use_streams:
+            self.send[c][:n_local].copy_(x_chunk)
+            self._gather(self.full[c], self.send[c], self.group)
+        else:
+            main = torch.cuda.current_stream(self.device)
+            self.send[c][:n_local].copy_(x_chunk)
+            self.staged[c].record(main)
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(self.staged[c])
+                self._gather(self.full[c], self.send[c], self.group)
+                self.ready[c].record(self.comm_stream)
+
+    def wait_chunk(self, c: int) -> torch.Tensor:
+        """Make the current stream wait for chunk ``c``'s exchange; returns the gathered ``[n_src, widths[c]]`` source."""
+        if self.ipc is not None:
+            self.ipc.end(c)
+        elif self.use_streams:
+            torch.cuda.current_stream(self.device).wait_event(self.ready[c])
+        return self.full[c][: self.n_src]
+
     def _spmm(self, x, out, hops=None):
         if self.kernel_events is None or not self.use_streams:
             self.plan.spmm(x, hops=hops, out=out)
@@ -602,6 +630,19 @@ def sharded_hop_spmm(layer: "PipelinedHopAggregation", x_local: torch.Tensor, ho
     return layer(x_local, hops=hops)
 
 
+def _cross_round_ok(layers, widths, H) -> bool:
+    """Cross-round pipelining applies when the run is distributed, every round is exchanged in chunks of ONE common width
+    and that width divides the rounds' input widths -- then the launch (chunk c, hop h) of round k writes exactly chunk
+    ``h * C_k + c`` of round k+1's input.  (``H2GCN_CROSS_ROUND=0`` switches it off.)"""
+    if len(layers) < 2 or layers[0].world == 1 or os.environ.get("H2GCN_CROSS_ROUND", "1") == "0":
+        return False
+    cw = layers[0].widths[0]
+    for k, layer in enumerate(layers):
+        if any(w != cw for w in layer.widths) or widths[k] % cw != 0 or layer.plan.n_selected(None) != H:
+            return False
+    return True
+
+
 class _ShardedFusedPropagation(torch.autograd.Function):
     """Row-sharded form of :class:`h2gcn_amd.layers._FusedPropagation`: the K aggregation rounds of H2GCN-K write
     straight into this rank's ``[n_local, W]`` concat buffer ``[r_K | r_0 | ... | r_{K-1}]``.  Round k all-gathers the
@@ -632,12 +673,43 @@ class _ShardedFusedPropagation(torch.autograd.Function):
             buf = out.view(n_local, total)
         if not reuse:
             buf[:, off[0]:off[0] + w0].copy_(r0)
-            for k in range(1, rounds + 1):
-                src = buf[:, off[k - 1]:off[k - 1] + widths[k - 1]]
-                dst = buf[:, off[k]:off[k] + widths[k]].unflatten(1, (H, widths[k - 1]))
-                hops_obj.pipeline(widths[k - 1])(src, out=dst)
+            layers = [hops_obj.pipeline(widths[k - 1]) for k in range(1, rounds + 1)]
+            if _cross_round_ok(layers, widths, H):
+                _ShardedFusedPropagation._cross_round(buf, layers, widths, off, H)
+            else:
+                for k in range(1, rounds + 1):
+                    src = buf[:, off[k - 1]:off[k - 1] + widths[k - 1]]
+                    dst = buf[:, off[k]:off[k] + widths[k]].unflatten(1, (H, widths[k - 1]))
+                    layers[k - 1](src, out=dst)
         ctx.hops_obj, ctx.rounds, ctx.widths, ctx.off = hops_obj, rounds, widths, off
         return buf
+
+    @staticmethod
+    def _cross_round(buf, layers, widths, off, H):
+        """The rounds with the exchange of round k+1 started as soon as its columns exist: round k is launched per (feature
+        chunk, hop) -- the hop matrices gather independently, so splitting the fused launch by hop costs only launch overhead
+        -- and the moment the launch (c, h) is enqueued, the chunk of ``r_k`` it writes (= chunk ``h * C_k + c`` of round
+        k+1's input) is staged and sent.  Round k+1's first exchange then runs under round k's remaining launches instead of
+        in front of round k+1 (the un-overlapped head of every round but the first).  Same launches per (row, hop, column),
+        hence the same bits as the round-by-round schedule."""
+        rounds = len(layers)
+        first = layers[0]
+        src0 = buf[:, off[0]:off[0] + widths[0]]
+        for c in range(first.C):
+            first.start_chunk(c, src0[:, first.offsets[c]:first.offsets[c] + first.widths[c]])
+        for k in range(1, rounds + 1):
+            cur = layers[k - 1]
+            nxt = layers[k] if k < rounds else None
+            dst = buf[:, off[k]:off[k] + widths[k]].unflatten(1, (H, widths[k - 1]))
+            for c in range(cur.C):
+                src = cur.wait_chunk(c)
+                cols = slice(cur.offsets[c], cur.offsets[c] + cur.widths[c])
+                if nxt is None:
+                    cur._spmm(src, dst[:, :, cols], None)          # last round: nothing waits for it, keep the fused launch
+                    continue
+                for h in range(H):
+                    cur._spmm(src, dst[:, h:h + 1, cols], [h])
+                    nxt.start_chunk(h * cur.C + c, dst[:, h, cols])
 
     @staticmethod
     def backward(ctx, grad):

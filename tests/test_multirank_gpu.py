@@ -169,21 +169,28 @@ def test_row_partitioned_propagation_reuse_is_invisible(tmp_path):
     data_dir = tmp_path / "data"
     _export_fixture(load_planetoid_golden("cora"), data_dir, "ind.cora")
     results = {}
-    for extra in ("", "--no_propagation_reuse"):
+    # also: the cross-round schedule of the sharded propagation (round k+1's exchange started per (chunk, hop) launch of
+    # round k) against the round-by-round one, and the other exchange form
+    configs = {"default": ("", {}, "ipc_engine"), "no_reuse": ("--no_propagation_reuse", {}, "ipc_engine"),
+               "round_by_round": ("--no_propagation_reuse", {"H2GCN_CROSS_ROUND": "0"}, "ipc_engine"),
+               "allgather": ("--no_propagation_reuse", {}, "allgather")}
+    for name, (extra, more_env, exchange) in configs.items():
         port = _free_port()
-        out_file = tmp_path / f"stats_{len(extra)}.json"
+        out_file = tmp_path / f"stats_{name}.json"
         procs = []
         for rank in range(2):
             env = dict(os.environ, H2GCN_ROOT=str(ROOT), DATA_DIR=str(data_dir), OUT_FILE=str(out_file), EPOCHS="8", EXTRA=extra,
-                       NETWORK="M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", H2GCN_EXCHANGE="ipc_engine", RANK=str(rank), LOCAL_RANK=str(rank),
-                       WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1")
+                       NETWORK="M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", H2GCN_EXCHANGE=exchange, RANK=str(rank), LOCAL_RANK=str(rank),
+                       WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1",
+                       **more_env)
             procs.append(subprocess.Popen([sys.executable, "-c", TRAIN_WORKER_TIMED], env=env, stdout=subprocess.PIPE,
                                           stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=900)[0].decode() for p in procs]
         assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-        results[extra] = json.loads(out_file.read_text())
-    for k in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_accuracy"):
-        assert results[""][k] == results["--no_propagation_reuse"][k], (k, results[""][k], results["--no_propagation_reuse"][k])
+        results[name] = json.loads(out_file.read_text())
+    for name in ("no_reuse", "round_by_round", "allgather"):
+        for k in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_accuracy"):
+            assert results["default"][k] == results[name][k], (name, k, results["default"][k], results[name][k])
 
 
 
