@@ -2,6 +2,7 @@
 """bench.py -- aggregated edges/s of the fused 1+2-hop SpMM (BASELINE.json metric) on N GPUs of one node.
 
     python bench.py                                  # N=1, products shape (configs[3]), 20 steps
+    python bench.py --gpus N --steps K --warmup W    # launches its N ranks itself (re-exec under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W       # configs[4]: same graph row-partitioned, strong scaling
 
@@ -24,6 +25,12 @@ import torch.distributed as dist
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+
+#: order-independent fingerprint of Y (sum of the fp32 bit patterns as int64) of the default single-GPU line per (shape, d):
+#: the per-row summation tree is canonical, so EVERY schedule -- any rank count, exchange, chunking, slice width -- must
+#: reproduce it bit for bit (SURVEY.md 8(e) "Determinism"); N > 1 lines report `checksum_matches_n1` against this table
+#: (measured: BENCH_r03.json / profiles/r04_checksums.json)
+N1_CHECKSUMS = {("products", 128): -26948829970322352}
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
 
@@ -214,7 +221,7 @@ def hbm_resident_leg(timeout_s=420):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def dry_exchange(a, world, rank, device, backend):
+def dry_exchange(a, world, rank, device, backend, to_stderr=False):
     """`--dry-exchange` (N > 1): FIRST-CONTACT check of every exchange form on this node before any big allocation --
     1 MiB shards, a handful of rounds each, per-candidate GB/s of landed bytes, which candidates fail and why.  Meant to
     be the first thing run on a multi-GPU box: it exercises the RCCL high-priority stream, the grouped send/recv form
@@ -280,10 +287,48 @@ def dry_exchange(a, world, rank, device, backend):
                 cand.close()
             except Exception:  # noqa: BLE001
                 pass
+    report = {"dry_exchange": table, "rejected": rejected, "n_gpus": world, "shard_bytes": per * d * 4,
+              "dist_backend": backend, "GPU_MAX_HW_QUEUES": hwq,
+              "note": "1 MiB shards: latency-dominated rates, a smoke test of every exchange form -- not a bandwidth figure"}
     if rank == 0:
-        print(json.dumps({"dry_exchange": table, "rejected": rejected, "n_gpus": world, "shard_bytes": per * d * 4,
-                          "dist_backend": backend, "GPU_MAX_HW_QUEUES": hwq,
-                          "note": "1 MiB shards: latency-dominated rates, a smoke test of every exchange form -- not a bandwidth figure"}))
+        print(json.dumps(report), file=sys.stderr if to_stderr else sys.stdout, flush=True)
+    return report
+
+
+def fail_line(a, why, rank=0, code=2):
+    """A bench run that cannot start still prints ONE JSON line (rank 0) -- with "error" and a null value -- and exits
+    non-zero, so that whoever parses the output sees why instead of a traceback."""
+    if rank == 0:
+        print(json.dumps({"metric": "aggregated edges/sec (1+2-hop SpMM)", "value": None, "unit": "edges/s", "n_gpus": a.gpus,
+                          "steps": a.steps, "warmup": a.warmup, "error": why}), flush=True)
+    raise SystemExit(code)
+
+
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: re-exec this command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` (one rank
+    per GPU, RCCL) and return its exit code.  With fewer than N GPUs visible (and not in the shared-GPU test mode) nothing
+    is launched: one JSON line with "error", exit code 2."""
+    import socket
+    import subprocess
+
+    share = os.environ.get("H2GCN_SHARE_GPU") == "1"
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < (1 if share else n_ranks):
+        ap = argparse.Namespace(gpus=n_ranks, steps=None, warmup=None)
+        try:
+            fail_line(ap, f"--gpus {n_ranks} but only {n_dev} GPU(s) are visible to this process")
+        except SystemExit as e:
+            return e.code
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL / the IPC exchange need on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def parse_chunks(spec, d):
@@ -322,13 +367,15 @@ def main():
                     help="N > 1: only smoke-test every exchange form with 1 MiB shards and print a table (no big allocation)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (same thing the documented
+        # `python -m torch.distributed.run ... bench.py --gpus N` form does) and pass rank 0's line through
+        raise SystemExit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit(f"--gpus {a.gpus} needs a torch.distributed.run launch with {a.gpus} ranks")
-        raise SystemExit(f"WORLD_SIZE={world} but --gpus {a.gpus}")
+        fail_line(a, f"WORLD_SIZE={world} but --gpus {a.gpus}", rank)
     if world > 1:
         # the exchange pipeline drives up to world + 1 streams (main, exchange / one per peer); HIP multiplexes streams
         # onto GPU_MAX_HW_QUEUES hardware queues (default 4) -- give every stream its own, before the runtime starts
@@ -336,7 +383,9 @@ def main():
         if a.dry_exchange:
             os.environ.setdefault("NCCL_DEBUG", "INFO")   # RCCL prints the algorithm / protocol / channels it picks
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: h2gcn_amd has no CPU fallback")
+        fail_line(a, "bench.py needs a GPU: h2gcn_amd has no CPU fallback", rank)
+    if os.environ.get("H2GCN_SHARE_GPU") != "1" and local_rank >= torch.cuda.device_count():
+        fail_line(a, f"rank {rank} has LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", 0)
     if os.environ.get("H2GCN_SHARE_GPU") == "1":  # test mode: several ranks on one GPU (RCCL refuses that -> gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -362,11 +411,22 @@ def main():
         dry_exchange(a, world, rank, device, backend)
         dist.destroy_process_group()
         return
+    first_contact = None
+    if world > 1 and os.environ.get("H2GCN_BENCH_SKIP_DRY") != "1":
+        # first contact with the node BEFORE any big allocation: every exchange form with 1 MiB shards (seconds); the table
+        # goes to stderr right away -- if a later stage dies, what worked and what did not is already on record -- and
+        # into the line's diagnostics
+        try:
+            first_contact = dry_exchange(a, world, rank, device, backend, to_stderr=True)
+        except Exception as e:  # noqa: BLE001 -- a report, never a reason to lose the measurement
+            first_contact = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                print(json.dumps({"dry_exchange_failed": first_contact["error"]}), file=sys.stderr, flush=True)
     cfg = synth.SHAPES[a.shape]
     n, d = cfg["n"], (a.d or cfg["d"])
     seeds = (synth.SEED_A1, synth.SEED_A2)
     r0, r1 = block_bounds(n, world, rank)
-    degs = [synth.synth_degrees(n, cfg["nnz_per_hop"], s, n) for s in seeds]
+    degs = synth.hop_degrees(cfg, seeds)
     csr = [synth.synth_hop_rows(degs[k], n, seeds[k], r0, r1, device) for k in range(2)]
     torch.cuda.synchronize()
     plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n,
@@ -472,6 +532,7 @@ def main():
         diagnostics["exchange"] = exchange
         diagnostics["calibration_ms_per_step"] = {k: v[0] for k, v in cands.items()}
         diagnostics["rejected"] = rejected
+        diagnostics["first_contact_dry_exchange"] = first_contact
         # comm-only and compute-only times of the chosen schedule (not part of the metric)
         diagnostics["exchange_only_ms"] = timed_ms(layer.exchange_only, 3)
         diagnostics["spmm_only_ms"] = timed_ms(
@@ -507,6 +568,13 @@ def main():
     if world > 1:
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
     kern_ms_max = float(kt.item())
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([kern_ms, float(sum(nnz_local)), float(algorithmic_bytes(nnz_local, r1 - r0, d, 2))], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": q, "kernel_ms": float(v[0]), "edges": int(v[1]), "algorithmic_bytes": int(v[2]), "achieved": float(v[2]) / (float(v[0]) * 1e-3) / 1e9,
+                     "frac": float(v[2]) / (float(v[0]) * 1e-3) / 1e9 / HBM_PEAK_GBPS} for q, v in enumerate(t_.tolist() for t_ in every)]
     # order-independent fingerprint of the result (same schedule => same bits for any number of ranks)
     ck = y.view(torch.int32).to(torch.int64).sum()
     if world > 1:
@@ -560,6 +628,14 @@ def main():
             "compulsory_frac": b_min / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         },
     }
+    if per_rank is not None:
+        # `achieved` / `frac` above are rank 0's shard kernel (its algorithmic bytes / its mean launch time); every rank's own
+        # figures, and the whole-job delivered rate over the step time (exchange included):
+        out["roofline"]["per_rank"] = per_rank
+        out["roofline"]["whole_job_GBps_over_step_time"] = sum(r_["algorithmic_bytes"] for r_ in per_rank) / (elapsed / a.steps) / 1e9
+    want = N1_CHECKSUMS.get((a.shape, d))
+    out["config"]["n1_checksum_expected"] = want
+    out["config"]["checksum_matches_n1"] = None if want is None else (y_checksum == want)
     if not a.no_adjoint:
         # backward launch dX = sum_k A_k^T dY[:, k, :] on the local shard: half of every training step
         # (reference h2gcn/models/H2GCN.py:66-74); secondary figure, not part of the metric
@@ -589,7 +665,15 @@ def main():
             out["roofline"]["traffic_source"] = live["source"]
             out["roofline"]["traffic_read_bytes"], out["roofline"]["traffic_write_bytes"] = live["read_bytes"], live["write_bytes"]
             out["roofline"]["traffic_over_algorithmic"] = live["bytes_per_launch"] / b_alg
-    if rank == 0 and world == 1 and not a.no_probe:
+    if rank == 0 and world == 1 and a.shape == "products" and not a.no_hbm_leg and os.environ.get("H2GCN_BENCH_CHILD") != "1":
+        del y
+        torch.cuda.empty_cache()
+        leg = hbm_resident_leg()
+        out["roofline"]["hbm_resident"] = leg
+        out["roofline"]["hbm_resident_frac"] = leg.get("frac")
+    if world > 1:
+        layer.close()          # collective: release the exchange buffers before rank 0 spends its seconds on the CPU legs
+    if rank == 0 and not a.no_probe:
         # live ceilings of this box at the kernel's gather working set (one column slice of X)
         slice_cols = min(plan.schedule(d)["slice_cols"], d)
         pr = probe_ceilings(n * slice_cols * 4 / 2**20, slice_cols * 4)
@@ -598,21 +682,24 @@ def main():
         out["roofline"]["ceilings"] = pr
         if pr.get("gather_GBps"):
             out["roofline"]["achieved_over_gather_ceiling"] = achieved / pr["gather_GBps"]
-    if rank == 0 and world == 1 and a.shape == "products" and not a.no_hbm_leg and os.environ.get("H2GCN_BENCH_CHILD") != "1":
-        del y
-        torch.cuda.empty_cache()
-        leg = hbm_resident_leg()
-        out["roofline"]["hbm_resident"] = leg
-        out["roofline"]["hbm_resident_frac"] = leg.get("frac")
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world > 1 and out["roofline"]["traffic"] is None:
+        out["roofline"]["traffic_source"] = "N > 1: PMC passes are collected on the single-GPU line only (same kernel, same per-row work)"
+    if rank == 0 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(csr, x_local, d, a.cpu_seconds)
+            # N > 1: rank 0's row block of the operands against the FULL embedding (regenerated: the same counter-based
+            # generator, any rows), timed after the measured region like the N = 1 leg
+            x_src = x_local if world == 1 else synth.synth_features(d, synth.SEED_X, 0, n, torch.device("cpu"))
+            out["cpu_baseline"] = cpu_baseline(csr, x_src, d, a.cpu_seconds)
+            if world > 1:
+                out["cpu_baseline"]["sample"] += f" [rank 0's row block of the {world}-way partition]"
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+    elif rank == 0:
+        out["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 1, "kind": "port", "sample": "skipped (--no-cpu-baseline)"}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
-        layer.close()
+        dist.barrier()        # the other ranks wait here while rank 0 times the CPU legs
         dist.destroy_process_group()
 
 

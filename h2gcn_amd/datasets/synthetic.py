@@ -61,7 +61,7 @@ class SyntheticShapeData:
         part = RowPartition.equal(n, world)
         r0, r1 = part.rows(rank)
         seeds = (synth.SEED_A1, synth.SEED_A2)
-        degs = [synth.synth_degrees(n, self.cfg["nnz_per_hop"], s, n) for s in seeds]
+        degs = synth.hop_degrees(self.cfg, seeds)
         csr = [synth.synth_hop_rows(degs[k], n, seeds[k], r0, r1, device) for k in range(2)]
         plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n, build_transpose=build_transpose)
         t = {"adj": None, "partition": part}

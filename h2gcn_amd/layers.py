@@ -219,8 +219,10 @@ class _FusedPropagation(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, r0: torch.Tensor, plan: HopPlan, rounds: int, out: Optional[torch.Tensor] = None, reuse: bool = False):
-        """``out``: a caller-owned ``[N, W]`` contiguous buffer to fill instead of a fresh one.  ``reuse``: ``out`` ALREADY
+    def forward(ctx, r0: torch.Tensor, plan: HopPlan, rounds: int, out: Optional[torch.Tensor] = None, reuse: bool = False,
+                private_grad: bool = False):
+        """``private_grad``: the caller guarantees that the gradient tensor this node's backward receives is a temporary
+        nobody else reads (see :func:`fused_propagation`).  ``out``: a caller-owned ``[N, W]`` contiguous buffer to fill instead of a fresh one.  ``reuse``: ``out`` ALREADY
         holds the propagation of this very ``r0`` (see :func:`fused_propagation`) -- nothing is computed, the buffer only
         enters the autograd graph (the backward needs none of the forward's values: the rounds are linear)."""
         n, w0 = r0.shape
@@ -247,6 +249,7 @@ class _FusedPropagation(torch.autograd.Function):
                 dst = buf[:, off[k]:off[k] + widths[k]].unflatten(1, (H, widths[k - 1]))
                 plan.spmm(src, out=dst)
         ctx.plan, ctx.rounds, ctx.widths, ctx.off = plan, rounds, widths, off
+        ctx.private_grad = bool(private_grad)
         return buf
 
     @staticmethod
@@ -255,10 +258,14 @@ class _FusedPropagation(torch.autograd.Function):
         H = plan.n_hops
         g_k = grad[:, off[K]:off[K] + widths[K]]  # d r_K: a view, read in place by the adjoint launch
         # The adjoint of round k is ADDED to the slot of r_{k-1} inside the incoming gradient itself (the library's
-        # accumulate flag: the `+=` rides on the adjoint's store) when that tensor is an ordinary dense one nobody else
-        # reads -- the gradient autograd hands to a backward is a temporary -- and the plan is in the wave-per-segment regime
-        # (the accumulating launch has no short-row variant).  Otherwise: a fresh tensor per round plus one `+=` pass.
-        dense = grad.is_contiguous() and isinstance(plan, HopPlan) and os.environ.get("H2GCN_BACKWARD_IN_PLACE", "1") != "0"
+        # accumulate flag: the `+=` rides on the adjoint's store) -- but ONLY when the caller has vouched that this tensor is a
+        # temporary of its own (`private_grad`: models.H2GCN sets it when the buffer's sole consumer is a layer whose
+        # backward allocates its input gradient, DropoutDense / Dense / Dropout).  Autograd itself gives no such guarantee
+        # (a user-supplied `out.backward(G)`, a hook or `retain_grad` on the buffer, a gradient shared with another node),
+        # so the default is a fresh tensor per round plus one `+=` pass.  Also needed: an ordinary dense gradient and the
+        # wave-per-segment regime (the accumulating launch has no short-row variant).
+        dense = (ctx.private_grad and grad.is_contiguous() and isinstance(plan, HopPlan)
+                 and os.environ.get("H2GCN_BACKWARD_IN_PLACE", "1") != "0")
         for k in range(K, 0, -1):
             slot = grad[:, off[k - 1]:off[k - 1] + widths[k - 1]]
             in_place = dense and plan.schedule(widths[k - 1], ld_src=grad.stride(0), adjoint=True)["segment_walk"] == "wave per segment"
@@ -268,7 +275,7 @@ class _FusedPropagation(torch.autograd.Function):
                 g_prev = plan.spmm_t(g_k.unflatten(1, (H, widths[k - 1])))
                 g_prev += slot
                 g_k = g_prev
-        return g_k, None, None, None, None
+        return g_k, None, None, None, None, None
 
 
 def concat_buffer(n_rows: int, width: int, device) -> torch.Tensor:
@@ -281,7 +288,7 @@ def concat_buffer(n_rows: int, width: int, device) -> torch.Tensor:
 
 
 def fused_propagation(plan: HopPlan, r0: torch.Tensor, rounds: int, out: Optional[torch.Tensor] = None,
-                      reuse: bool = False) -> torch.Tensor:
+                      reuse: bool = False, private_grad: bool = False) -> torch.Tensor:
     """``[r_K | r_0 | ... | r_{K-1}]`` for ``rounds = K`` aggregation rounds, without intermediate copies.
 
     ``out`` / ``reuse``: the propagation is a deterministic function of ``(plan, r0)``, and an epoch of the reference evaluates
@@ -289,7 +296,11 @@ def fused_propagation(plan: HopPlan, r0: torch.Tensor, rounds: int, out: Optiona
     epoch's training forward recomputes exactly the buffer the evaluation has just produced whenever nothing stochastic
     precedes the propagation (H2GCN's default setup: the only dropout sits behind it).  A caller that knows this
     (``models.H2GCN``) lets the evaluation fill a persistent buffer (``out=``) and hands the same buffer to the training
-    forward with ``reuse=True``: same bits, one propagation per epoch instead of two."""
+    forward with ``reuse=True``: same bits, one propagation per epoch instead of two.
+
+    ``private_grad``: promise that the gradient arriving for the returned buffer is a temporary no one else holds; the
+    backward then accumulates the rounds' adjoints into its slots in place (bit-identical, one pass and one tensor less per
+    round).  Leave it off when the buffer's gradient may be observed (hooks, ``retain_grad``, an explicit ``backward(G)``)."""
     if rounds < 1:
         raise ValueError("rounds must be >= 1")
     if r0.dim() != 2 or r0.shape[0] != plan.n_cols or plan.n_rows != plan.n_cols:
@@ -297,7 +308,7 @@ def fused_propagation(plan: HopPlan, r0: torch.Tensor, rounds: int, out: Optiona
     if reuse and out is None:
         raise ValueError("fused_propagation: reuse=True needs the buffer that holds the propagation (out=)")
     if r0.requires_grad and torch.is_grad_enabled():
-        return _FusedPropagation.apply(r0, plan, rounds, out, reuse)
+        return _FusedPropagation.apply(r0, plan, rounds, out, reuse, private_grad)
     return _FusedPropagation.forward(_NoCtx(), r0, plan, rounds, out, reuse)
 
 
@@ -376,13 +387,22 @@ class DropoutDense(torch.nn.Module):
     forward, keyed by ``(seed, step)``; ``step`` lives in a device counter bumped by a stream-ordered op, so a replayed
     hipGraph draws a fresh mask every epoch."""
 
+    _instances = 0   # per-process construction counter: the default salt of a layer's mask stream
+
     def __init__(self, input_dim: int, units: int, use_bias: bool, drop_prob: float, seed: Optional[int] = None):
         super().__init__()
         self.kernel = torch.nn.Parameter(torch.empty(input_dim, units))
         torch.nn.init.xavier_uniform_(self.kernel)
         self.bias = torch.nn.Parameter(torch.zeros(units)) if use_bias else None
         self.drop_prob = float(drop_prob)
-        self.seed = int(torch.initial_seed() if seed is None else seed) & 0x7FFFFFFFFFFFFFFF
+        if seed is None:
+            # the mask is a pure function of (seed, step, row, column group) and every layer's step counter advances in
+            # lock step: without a per-layer salt two DropoutDense layers of one model would draw IDENTICAL masks.  (Models
+            # built in the same order under the same torch seed get the same streams; H2GCN passes seed = initial_seed + layer
+            # index explicitly.)
+            seed = torch.initial_seed() + 0x632BE59BD9B4E019 * (DropoutDense._instances + 1)
+            DropoutDense._instances += 1
+        self.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             # row-partitioned runs: the kernels index the mask by LOCAL row, so every rank gets its own stream (otherwise row i
             # of every shard would be dropped identically)

@@ -6,6 +6,10 @@ cross-entropy / argmax agreement with ``mask / mean(mask)`` and take the mean, i
 same logits (``h2gcn/models/H2GCN.py:66-74, 77-107``).  Here a *set* is ``(labels [N, C], row weights [N])``; all sets of a
 call share one read of the logits.  GPU only, fp32, ``C <= 64``: anything else is the caller's business (``models/_metrics.py``
 keeps the plain torch expressions for those cases); the HIP library is required -- there is no CPU path in this module.
+
+Divergence on non-finite logits (documented, deliberate): the reference multiplies every row's term by its mask weight, so a
+NaN / Inf logit in a row the mask EXCLUDES still poisons the result (``0 * NaN``); the kernels skip rows of zero weight, so only
+rows a mask includes can make its loss / accuracy non-finite.
 """
 import ctypes as C
 from typing import Sequence, Tuple

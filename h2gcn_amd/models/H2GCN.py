@@ -512,7 +512,8 @@ class H2GCN(torch.nn.Module):
                     # A dense layer without a dropout in front runs on the same kernels with the mask off: its weight
                     # gradient X^T G is a reduction over all N rows into a tiny [K, units] result, which general GEMM tiles
                     # handle badly (products shape, [N,100]^T [N,64]: 3.3 ms stock, 0.5 ms here)
-                    layer = L.DropoutDense(width, conf["units"], conf["use_bias"], pending_dropout or 0.0)
+                    layer = L.DropoutDense(width, conf["units"], conf["use_bias"], pending_dropout or 0.0,
+                                           seed=torch.initial_seed() + 0x632BE59BD9B4E019 * (ind + 1))   # one mask stream per layer
                     pending_dropout = None
                 else:
                     layer = Dense(width, conf["units"], conf["use_bias"])
@@ -649,7 +650,8 @@ class H2GCN(torch.nn.Module):
                 # rows of the same buffer, one exchange per round)
                 _, end, K, tags = self.fused
                 sharded_hops = hasattr(adjhops, "fused_propagation")
-                propagate = adjhops.fused_propagation if sharded_hops else functools.partial(L.fused_propagation, adjhops)
+                propagate = adjhops.fused_propagation if sharded_hops else functools.partial(
+                    L.fused_propagation, adjhops, private_grad=self._buffer_grad_is_private(end))
                 if self.reuse_propagation and inputs.is_cuda:
                     # (row-partitioned runs: every rank takes the same branch -- the decision depends only on the call
                     # sequence, which is the same on all ranks)
@@ -657,7 +659,12 @@ class H2GCN(torch.nn.Module):
                     width = inputs.shape[1] * sum(H_ ** k for k in range(K + 1))
                     buf = self._propagation_buffer(inputs.shape[0], width, inputs.device)
                     plan_ = getattr(adjhops, "plan", adjhops)
-                    key = (self._weights_tag, id(adjhops), getattr(plan_, "values_version", 0), feat_key, tuple(inputs.shape), K)
+                    # the parameters in front of the propagation enter through their autograd version counters (every in-place
+                    # torch update bumps them; KerasAdam's raw-pointer kernel bumps them explicitly), so an ordinary torch
+                    # training loop can never adopt a buffer computed from older weights; `note_update()` stays as the
+                    # explicit form for anything that writes parameters behind torch's back
+                    versions = tuple(p._version for p in self.parameters())
+                    key = (self._weights_tag, versions, id(adjhops), getattr(plan_, "values_version", 0), feat_key, tuple(inputs.shape), K)
                     if not torch.is_grad_enabled():          # evaluation: fill the persistent buffer
                         self._prop_key = None
                         inputs = propagate(inputs, K, out=buf)
@@ -689,6 +696,16 @@ class H2GCN(torch.nn.Module):
         if tagged_out is not None:
             tagged_out.update(tagged)
         return inputs
+
+    def _buffer_grad_is_private(self, end: int) -> bool:
+        """True when the concat buffer feeds exactly one layer whose backward ALLOCATES its input gradient (DropoutDense, Dense,
+        Dropout) and nothing else can see it (no tag on the block's last layer): only then may the propagation's backward
+        accumulate into that gradient tensor in place."""
+        if (end - 1) in self.tags:
+            return False
+        while end < len(self.layer_objs) and isinstance(self.layer_objs[end], torch.nn.Identity) and end not in self.tags:
+            end += 1       # (the placeholder a `D` leaves when the following dense layer applies the dropout itself)
+        return end < len(self.layer_objs) and isinstance(self.layer_objs[end], (L.DropoutDense, Dense, torch.nn.Dropout))
 
     def restore_sparse_inputs(self) -> None:
         """Undo what ``SparseDropout`` did to the shared sparse feature operand (after the backward pass)."""

@@ -46,9 +46,7 @@ class KerasAdam(torch.optim.Optimizer):
             # one step counter per group, on the device of its first parameter (host copy for the CPU formula)
             if "step_dev" not in group:
                 group["step_dev"] = torch.zeros(1, dtype=torch.int64, device=ps[0].device)
-                group["step_host"] = 0
             group["step_dev"] += 1
-            group["step_host"] += 1
             fast = [p for p in ps if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.device == group["step_dev"].device]
             slow = [p for p in ps if not any(p is q for q in fast)]
             if fast:
@@ -63,9 +61,15 @@ class KerasAdam(torch.optim.Optimizer):
                         arr(*[s["m"].data_ptr() for s in states]), arr(*[s["v"].data_ptr() for s in states]),
                         (C.c_int64 * n)(*[p.numel() for p in fast]), lr, b1, b2, eps,
                         C.c_void_p(group["step_dev"].data_ptr()), 0, C.c_void_p(stream)))
+                # the kernel wrote the parameters through raw pointers: tell autograd's version counters, so that anything
+                # keyed by `p._version` (models.H2GCN's propagation reuse) sees the update like after any in-place torch op
+                torch._C._increment_version(fast)
+            if slow and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("KerasAdam: parameters outside the one-launch kernel (CPU / non-fp32 / non-contiguous) cannot be "
+                                   "stepped inside a hipGraph capture")
+            t = int(group["step_dev"].item()) if slow else 0   # ONE counter: the device one (a replayed graph advances it too)
             for p in slow:
                 st = self._state(p)
-                t = group["step_host"]
                 one, tb1, tb2 = (torch.tensor(x, dtype=torch.float32) for x in (1.0, b1, b2))   # fp32 like the kernel
                 alpha = (torch.tensor(lr, dtype=torch.float32) * torch.sqrt(one - tb2 ** t) / (one - tb1 ** t)).item()
                 g = p.grad
@@ -73,6 +77,28 @@ class KerasAdam(torch.optim.Optimizer):
                 st["v"].add_((g * g - st["v"]) * (one - tb2).item())
                 p.sub_((st["m"] * alpha) / (st["v"].sqrt() + eps))
         return loss
+
+
+    def load_state_dict(self, state_dict) -> None:
+        """Restore INTO the existing tensors: a captured training hipGraph holds the addresses of ``m``, ``v`` and the step
+        counter, so a restore (``BestSnapshot.restore``) must not replace them with fresh allocations the graph knows nothing
+        about."""
+        old_state = {p: dict(st) for p, st in self.state.items()}
+        old_steps = [g.get("step_dev") for g in self.param_groups]
+        super().load_state_dict(state_dict)
+        with torch.no_grad():
+            for p, st in self.state.items():
+                for name in ("m", "v"):
+                    kept = old_state.get(p, {}).get(name)
+                    if kept is not None and name in st and kept is not st[name] and kept.shape == st[name].shape:
+                        kept.copy_(st[name])
+                        st[name] = kept
+            for g, kept in zip(self.param_groups, old_steps):
+                new = g.get("step_dev")
+                if kept is not None and new is not None and kept is not new:
+                    kept.copy_(new.to(kept.device))
+                    g["step_dev"] = kept
+                g.pop("step_host", None)   # (state dicts written before the single-counter change)
 
 
 class KerasRMSprop(torch.optim.Optimizer):

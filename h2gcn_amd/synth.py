@@ -75,6 +75,39 @@ def synth_degrees(n_rows: int, nnz_target: int, seed: int, n_cols: int, alpha: f
     return np.minimum(deg, n_cols)
 
 
+def synth_degrees_lognormal(n_rows: int, nnz_target: int, seed: int, n_cols: int, sigma: float = 1.35,
+                              empty_frac: float = 0.01) -> np.ndarray:
+    """Raw degrees with a long LOW-degree body: ``exp(sigma * N(0, 1))`` scaled to the target total, rounded, non-empty rows
+    at least 1 -- degrees start at 1 (the rescaled Pareto of :func:`synth_degrees` has a minimum of ~nnz/3n), the bulk of
+    the ROWS is short and the bulk of the EDGES sits in medium / long rows, which is how real co-purchase / citation
+    degree sequences look (sigma = 1.35 at mean 50: median 20, ~43 % of the rows below 16, ~3 % at 256 or more)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    raw = np.exp(sigma * rng.standard_normal(n_rows))
+    raw[rng.random(n_rows) < empty_frac] = 0.0
+    total = raw.sum()
+    if total <= 0 or nnz_target <= 0:
+        return np.zeros(n_rows, dtype=np.int64)
+    deg = np.floor(raw * (nnz_target / total) + 0.5).astype(np.int64)
+    deg[(raw > 0) & (deg < 1)] = 1
+    return np.minimum(deg, n_cols)
+
+
+def hop_degrees(cfg: dict, seeds=None) -> list:
+    """Raw degree sequences of the hop matrices of one entry of :data:`SHAPES` (identical on every rank)."""
+    seeds = seeds or (SEED_A1, SEED_A2)
+    nnz = cfg["nnz_per_hop"]
+    nnz = list(nnz) if isinstance(nnz, (list, tuple)) else [nnz] * len(seeds)
+    spec = cfg.get("degrees")
+    out = []
+    for k, s in enumerate(seeds):
+        if spec is None:
+            out.append(synth_degrees(cfg["n"], nnz[k], s, cfg["n"]))
+        else:
+            sp = spec[k] if isinstance(spec, (list, tuple)) else spec
+            out.append(synth_degrees_lognormal(cfg["n"], nnz[k], s, cfg["n"], sigma=sp["sigma"]))
+    return out
+
+
 def synth_hop_rows_np(raw_deg: np.ndarray, n_cols: int, seed: int, r0: int, r1: int
                       ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """CSR of rows [r0, r1) (local row pointers), numpy: (rowptr int64, colidx int32, vals float32)."""
@@ -152,5 +185,12 @@ SHAPES = {
     # from what the cache adds.  X = 8.2 GB (4.1 GB per 64-column slice):
     "hbm16m": dict(n=16_000_000, nnz_per_hop=120_000_000, d=128),      # products' edge count, mean degree 7.5
     "products_x6": dict(n=16_000_000, nnz_per_hop=800_000_000, d=128),  # products' degree distribution (mean 50)
+    # not BASELINE configs: MIXED segment classes in one launch (round 4: binned short-segment list next to the tile walk).
+    # The reference's own operands are bimodal by construction -- the exact-2-hop ring is ~8x denser than the 1-hop one
+    # (h2gcn/datasets/_dataset.py:138-158; Cora: mean 3.9 / 31.9) -- and real degree sequences start at 1:
+    "h2gcn_like": dict(n=2_000_000, nnz_per_hop=[16_000_000, 200_000_000], d=128,
+                       degrees=[dict(sigma=1.0), dict(sigma=1.0)]),       # A1 mean 8 (median 5), A2 mean 100 (median 60)
+    "products_tail": dict(n=2_400_000, nnz_per_hop=120_000_000, d=128,
+                          degrees=dict(sigma=1.35)),                      # products' |V|, |E|; degrees from 1, ~43 % of rows < 16
 }
 SEED_A1, SEED_A2, SEED_X = 123, 124, 125

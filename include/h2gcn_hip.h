@@ -356,6 +356,10 @@ int h2gcn_dropout_dense_backward_f32(const float* X_dev, int64_t ldx, int64_t n_
  *
  * Rows whose weight is zero in every set are not read; a label matrix is read only at the rows of non-zero weight.  Per-row
  * terms are fp32, the sums over rows run in fp64 per workgroup and are combined in a fixed order (deterministic).
+ * DIVERGENCE from the reference on non-finite logits: the reference MULTIPLIES every row's term by its mask weight
+ * (_metrics.py:12-14, 22-24), so a NaN / Inf logit in a row the mask excludes still yields NaN there (0 * NaN); here such a
+ * row is skipped and the result stays finite.  Rows the mask includes propagate NaN / Inf exactly as the reference does, so a
+ * diverged model is still visible through any set that covers the affected rows.
  * h2gcn_masked_ce_backward_f32 is the gradient of loss (one set) with respect to Z, times the scalar *gscale_dev (NULL = 1):
  *     dZ[n, c] = g * w[n] * ( softmax(Z[n])[c] * sum_c' Y[n, c'] - Y[n, c] )     (rows of weight 0: zeros).
  *   Z  fp32 [n_rows, C] row stride ldz, C <= 64      Y, ldy, w  HOST arrays of n_sets (<= H2GCN_METRICS_MAX_SETS) device pointers /

@@ -352,8 +352,7 @@ def _train_epochs(model, tensors, n_epochs, pattern="te"):
                 model.train()
                 opt.zero_grad(set_to_none=True)
                 model.loss(model(*args), tensors["y_train"], tensors["train_mask"]).backward()
-                opt.step()
-                model.note_update()
+                opt.step()          # (no model.note_update(): an ordinary torch loop -- the reuse key follows p._version)
             else:
                 model.eval()
                 with torch.no_grad():
@@ -361,7 +360,7 @@ def _train_epochs(model, tensors, n_epochs, pattern="te"):
     return [p.detach().clone() for p in model.parameters()], logits.clone()
 
 
-@pytest.mark.parametrize("pattern", ["te", "tte", "et"])
+@pytest.mark.parametrize("pattern", ["te", "tte", "et", "ett"])
 def test_propagation_reuse_is_invisible_in_the_results(tmp_path, monkeypatch, pattern):
     """The training forward adopts the propagation buffer the evaluation has just filled (one propagation per epoch instead
     of two).  Same bits as recomputing it -- parameters after 6 epochs and the final logits -- also when the train / evaluate
@@ -384,6 +383,58 @@ def test_propagation_reuse_is_invisible_in_the_results(tmp_path, monkeypatch, pa
     for a, b in zip(results["1"][0], results["0"][0]):
         assert torch.equal(a, b)
     assert torch.equal(results["1"][1], results["0"][1])
+
+
+def test_fused_propagation_leaves_a_user_supplied_gradient_alone(tmp_path):
+    """`out.backward(G)` with a caller-owned G: the propagation's backward must not accumulate into G's slots (it may only do
+    that when the model vouches that the gradient is a private temporary, `private_grad=True` -- same bits either way)."""
+    from h2gcn_amd import layers as L
+    g, data, tensors, setup, model = _setup(tmp_path)
+    plan = tensors["adj_hops"]
+    torch.manual_seed(3)
+    r0 = torch.randn(plan.n_cols, 16, device="cuda:0", requires_grad=True)
+    grads = {}
+    for private in (False, True):
+        r0.grad = None
+        out = L.fused_propagation(plan, r0, 2, private_grad=private)
+        G = torch.randn(out.shape, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(5))
+        keep = G.clone()
+        out.backward(G)
+        if not private:
+            assert torch.equal(G, keep), "the caller's gradient tensor was modified"
+        grads[private] = r0.grad.clone()
+    assert torch.equal(grads[False], grads[True])
+
+
+def test_dropout_dense_layers_of_one_model_draw_different_masks(tmp_path):
+    from h2gcn_amd import layers as L
+    torch.manual_seed(0)
+    a, b = L.DropoutDense(64, 8, False, 0.5), L.DropoutDense(64, 8, False, 0.5)
+    assert a.seed != b.seed
+    g, data, tensors, setup, model = _setup(tmp_path, "M64-R-T1-G-V-T2-G-V-C1-C2-D0.5-M32-D0.5-MO")
+    seeds = [l.seed for l in model.layer_objs if isinstance(l, L.DropoutDense)]
+    assert len(seeds) == 2 and seeds[0] != seeds[1]
+
+
+def test_keras_adam_restores_into_its_existing_state_tensors():
+    """load_state_dict (BestSnapshot.restore) must copy INTO m / v / the step counter: a captured training hipGraph holds
+    their addresses."""
+    from h2gcn_amd.optim import KerasAdam
+    p = torch.nn.Parameter(torch.ones(8, device="cuda:0"))
+    opt = KerasAdam([p], lr=0.1)
+    p.grad = torch.ones_like(p)
+    v0 = p._version
+    opt.step()
+    assert p._version > v0                      # the raw-pointer kernel told autograd's version counter
+    saved = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items()}
+    import copy
+    saved = copy.deepcopy(opt.state_dict())
+    ptrs = (opt.state[p]["m"].data_ptr(), opt.state[p]["v"].data_ptr(), opt.param_groups[0]["step_dev"].data_ptr())
+    opt.step(); opt.step()
+    opt.load_state_dict(saved)
+    assert ptrs == (opt.state[p]["m"].data_ptr(), opt.state[p]["v"].data_ptr(), opt.param_groups[0]["step_dev"].data_ptr())
+    assert int(opt.param_groups[0]["step_dev"].item()) == 1
+    assert torch.equal(opt.state[p]["m"], saved["state"][0]["m"])
 
 
 def test_propagation_reuse_is_off_when_a_dropout_precedes_the_propagation(tmp_path):

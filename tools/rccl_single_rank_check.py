@@ -1,6 +1,8 @@
+"""RCCL (backend "nccl") at world size 1 on this box's GPU: the process-group options, collectives and IPC set-up the
+row-partitioned path uses on a multi-GPU node (run by tests/test_multirank_gpu.py::test_rccl_backend_at_world_size_one)."""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.getcwd())
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29555", RANK="0", WORLD_SIZE="1")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29555"), RANK="0", WORLD_SIZE="1")
 from h2gcn_amd.partition import init_rccl_process_group, _all_gather_rows, _all_gather_rows_p2p, _reduce_scatter_rows
 torch.cuda.set_device(0); dev = torch.device("cuda", 0)
 init_rccl_process_group(dev, 120.0)  # with the collective timeout bench.py passes
@@ -11,6 +13,12 @@ out = _reduce_scatter_rows(send.clone(), 3, 0); assert torch.equal(out, send)
 s = torch.cuda.Stream(priority=-1)
 with torch.cuda.stream(s):
     dist.all_gather_into_tensor(full, send)
+send_t, recv_t = torch.ones(8, device=dev), torch.zeros(8, device=dev)     # the grouped send/recv form (to self at world 1)
+for w_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, send_t, 0), dist.P2POp(dist.irecv, recv_t, 0)]):
+    w_.wait()
+assert torch.equal(send_t, recv_t)
+rs_in = torch.arange(6, dtype=torch.float32, device=dev); rs_out = torch.zeros(6, device=dev)
+dist.reduce_scatter_tensor(rs_out, rs_in); assert torch.equal(rs_out, rs_in)
 objs = [None]; dist.all_gather_object(objs, b"blob")            # the bootstrap channel of the IPC exchange, over RCCL
 assert objs == [b"blob"]
 from h2gcn_amd.partition import IpcExchange
