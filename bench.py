@@ -518,12 +518,16 @@ def main():
                     why = f"warm-up: {type(e).__name__}: {e}"
                 if not all_ok(why is None):
                     rejected[key] = why or "warm-up failed on another rank"
+                    if rank == 0:
+                        print(json.dumps({"calibration": key, "rejected": rejected[key], "n_gpus": world}), file=sys.stderr, flush=True)
                     try:
                         cand.close()       # collective: every rank is here
                     except Exception:  # noqa: BLE001
                         pass
                     continue
                 cands[key] = (timed_ms(lambda: cand(x_local, out=y), 3), cand, ex, spec)
+                if rank == 0:   # on record at once: if a later candidate takes the job down, what was measured survives in stderr
+                    print(json.dumps({"calibration": key, "ms_per_step": cands[key][0], "n_gpus": world}), file=sys.stderr, flush=True)
         if not cands:
             raise SystemExit(f"no exchange schedule works: {rejected}")
         best = min(cands, key=lambda k: cands[k][0])

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_HOPS = 8
 
 OK = 0
@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = (
     "h2gcn_spmm_hops_f32",
     "h2gcn_spmm_hops_T_f32",
     "h2gcn_plan_schedule",
+    "h2gcn_plan_segment_classes",
     "h2gcn_spmm_workspace_bytes",
     "h2gcn_spmm_hops_opts_f32",
     "h2gcn_spmm_hops_T_opts_f32",
@@ -164,6 +165,9 @@ def lib() -> C.CDLL:
     ]
     L.h2gcn_plan_schedule.restype = C.c_int
     L.h2gcn_plan_schedule.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int64, C.c_int32] + [C.POINTER(C.c_int32)] * 4
+    if hasattr(L, "h2gcn_plan_segment_classes"):   # (absent from pre-ABI-4 builds loaded for A/B runs)
+        L.h2gcn_plan_segment_classes.restype = C.c_int
+        L.h2gcn_plan_segment_classes.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int64, C.c_int32] + [C.POINTER(C.c_int64)] * 3
     L.h2gcn_spmm_workspace_bytes.restype = C.c_size_t
     L.h2gcn_spmm_workspace_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int32]
     L.h2gcn_spmm_hops_opts_f32.restype = C.c_int
@@ -241,7 +245,9 @@ def lib() -> C.CDLL:
     L.h2gcn_xchg_destroy.restype = None
     L.h2gcn_xchg_destroy.argtypes = [C.c_void_p]
     got = L.h2gcn_abi_version()
-    if got != ABI_VERSION:
+    # (an explicitly named older build -- H2GCN_HIP_LIBRARY, the A/B tools -- may lack entry points added later: ABI 4 only
+    # ADDED h2gcn_plan_segment_classes)
+    if got != ABI_VERSION and not (os.environ.get("H2GCN_HIP_LIBRARY") and got == 3):
         raise RuntimeError(f"{path}: ABI version {got}, this front end expects {ABI_VERSION}")
     _LIB = L
     return L

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -62,6 +63,9 @@ struct HopOperand {  // one CSR, device pointers
     const float* vals = nullptr;
     int64_t nnz = 0;
     std::vector<int64_t> long_rows;  // rows whose segment has >= long_row_threshold nonzeros, ascending
+    std::vector<uint8_t> len8;       // min(segment length, 255) per row: what the segment-class bins are built from
+    int64_t n_short = 0, nnz_short = 0;  // segments of at most short_max nonzeros (empty ones included) / their nonzeros
+    int64_t nnz_long = 0;                // nonzeros of the long segments
     const uint32_t* perm = nullptr;  // adjoint operands built with H2GCN_PLAN_KEEP_PERMUTATION: source entry of entry i
 };
 
@@ -70,6 +74,13 @@ struct LongList {
     int n = 0;
     LongList() = default;
     LongList(LongList&&) noexcept = default;
+};
+
+struct ClassLists {   // rows (int32, ascending) of the short and of the medium bin of one operand / hop selection
+    DeviceBuf short_dev, med_dev;
+    int64_t n_short = 0, nnz_short = 0, n_med = 0;
+    ClassLists() = default;
+    ClassLists(ClassLists&&) noexcept = default;
 };
 
 }  // namespace
@@ -89,9 +100,26 @@ struct h2gcn_plan {
     // long-segment lists are specific to a hop selection; built on first use, then cached
     mutable std::mutex mu;
     mutable std::map<uint64_t, LongList> long_cache;  // key = mask | (adjoint << 32)
+    // segment-class bins besides the long lists: forward -- per hop (key = hop | 1 << 40) the rows whose segment is short /
+    // medium; adjoint -- per hop selection (key = mask | 1 << 32) the rows whose segments of ALL selected hops are short /
+    // the rows that are neither that nor owned by the long path
+    mutable std::map<uint64_t, ClassLists> class_cache;
+    int short_max = -1;      // longest segment of the short class (min(kShortMax, long_threshold - 1)); -1: no binning
+    double short_min_frac = 0.05;  // a launch uses the list when at least this share of its segments is short
 };
 
 namespace h2gcn {
+// one-time operand check of plan_create: any column id outside [0, n_cols) raises the flag
+__global__ void check_colidx_kernel(const int32_t* __restrict__ colidx, int64_t nnz, int64_t n_cols, int* flag) {
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t c = colidx[i];
+        bad |= (c < 0) | ((int64_t)c >= n_cols);
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+void launch_in_tile_short(bool sum, const LaunchParams& p, int slice, bool off32, bool fb4, dim3 grid, hipStream_t stream);
 int transpose_csr_device(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                          const float* vals, int64_t** t_rowptr_out, int32_t** t_colidx_out, float** t_vals_out,
                          uint32_t** perm_out_keep, hipStream_t stream, std::string* err);
@@ -129,6 +157,82 @@ void collect_long_rows(const std::vector<int64_t>& rowptr, int64_t n_rows, int t
     out.clear();
     for (int64_t r = 0; r < n_rows; ++r)
         if (rowptr[r + 1] - rowptr[r] >= threshold) out.push_back(r);
+}
+
+// Segment lengths of one operand, clipped to a byte: the class of every segment (short / medium / long) follows from it.
+void collect_segment_lengths(const std::vector<int64_t>& rowptr, int64_t n_rows, int short_max, int long_threshold, HopOperand& op) {
+    op.len8.resize((size_t)n_rows);
+    op.n_short = op.nnz_short = op.nnz_long = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t len = rowptr[r + 1] - rowptr[r];
+        op.len8[(size_t)r] = (uint8_t)(len > 255 ? 255 : len);
+        if (len <= short_max) {
+            ++op.n_short;
+            op.nnz_short += len;
+        } else if (len >= long_threshold) {
+            op.nnz_long += len;
+        }
+    }
+}
+
+// The short and medium bins of a launch (cached in the plan): forward -- hop `k`'s rows by the class of their segment;
+// adjoint -- the rows whose segments of every hop in `mask` are short, and the rows that are neither that nor contain a
+// long segment (those belong to the long list).
+int get_class_lists(const h2gcn_plan* plan, bool adjoint, int k, uint32_t mask, const ClassLists** out) {
+    *out = nullptr;
+    const std::vector<HopOperand>& ops = adjoint ? plan->adj : plan->fwd;
+    const int64_t n_rows = adjoint ? plan->n_cols : plan->n_rows;
+    if (plan->short_max < 0 || n_rows > 0x7fffffffLL) return H2GCN_OK;
+    const uint64_t key = adjoint ? ((uint64_t)mask | (1ull << 32)) : ((uint64_t)k | (1ull << 40));
+    std::lock_guard<std::mutex> lock(plan->mu);
+    auto it = plan->class_cache.find(key);
+    if (it == plan->class_cache.end()) {
+        std::vector<int32_t> h_short, h_med;
+        int64_t nnz = 0;
+        const int sm = plan->short_max;
+        if (!adjoint) {
+            const std::vector<uint8_t>& len = ops[k].len8;
+            const std::vector<int64_t>& longs = ops[k].long_rows;   // ascending
+            h_short.reserve((size_t)ops[k].n_short);
+            size_t li = 0;
+            for (int64_t r = 0; r < n_rows; ++r) {
+                while (li < longs.size() && longs[li] < r) ++li;
+                const bool is_long = li < longs.size() && longs[li] == r;
+                if (len[(size_t)r] <= sm) { h_short.push_back((int32_t)r); nnz += len[(size_t)r]; }
+                else if (!is_long) h_med.push_back((int32_t)r);
+            }
+        } else {
+            std::vector<const uint8_t*> sel;
+            std::vector<uint8_t> any_long((size_t)n_rows, 0);
+            for (int h = 0; h < plan->n_hops; ++h)
+                if (mask & (1u << h)) {
+                    sel.push_back(ops[h].len8.data());
+                    for (int64_t r : ops[h].long_rows) any_long[(size_t)r] = 1;
+                }
+            for (int64_t r = 0; r < n_rows; ++r) {
+                bool all = true;
+                int64_t z = 0;
+                for (const uint8_t* l : sel) { all = all && l[r] <= sm; z += l[r]; }
+                if (all) { h_short.push_back((int32_t)r); nnz += z; }
+                else if (!any_long[(size_t)r]) h_med.push_back((int32_t)r);
+            }
+        }
+        ClassLists fresh;
+        fresh.n_short = (int64_t)h_short.size();
+        fresh.nnz_short = nnz;
+        fresh.n_med = (int64_t)h_med.size();
+        if (fresh.n_short > 0) {
+            H2GCN_HIP_TRY(hipMalloc(&fresh.short_dev.p, h_short.size() * sizeof(int32_t)));
+            H2GCN_HIP_TRY(hipMemcpy(fresh.short_dev.p, h_short.data(), h_short.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        if (fresh.n_med > 0) {
+            H2GCN_HIP_TRY(hipMalloc(&fresh.med_dev.p, h_med.size() * sizeof(int32_t)));
+            H2GCN_HIP_TRY(hipMemcpy(fresh.med_dev.p, h_med.data(), h_med.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        it = plan->class_cache.emplace(key, std::move(fresh)).first;
+    }
+    *out = &it->second;
+    return H2GCN_OK;
 }
 
 int check_rowptr(const std::vector<int64_t>& rowptr, int64_t n_rows, int hop) {
@@ -237,7 +341,18 @@ struct LaunchShape {
     int64_t ld_src;
     int d;
     bool src_line_aligned;  // every gathered row starts on a 128-byte line: base pointer and row stride (and hop offsets)
+    // binned short segments available to this launch (see get_short_list)
+    const int32_t* short_list[H2GCN_MAX_HOPS];
+    int64_t short_count[H2GCN_MAX_HOPS];
+    const int32_t* med_list[H2GCN_MAX_HOPS];
+    int64_t med_count[H2GCN_MAX_HOPS];
+    int n_short_lists;      // forward: n_sel, adjoint: 1 (0: none)
+    double short_frac;      // share of the launch's segments (adjoint: output rows) the lists cover
+    double short_nnz_frac;  // share of its nonzeros
 };
+
+LaunchShape shape_of(const h2gcn_plan* plan, uint32_t mask, bool adjoint);
+int fill_short(const h2gcn_plan* plan, uint32_t mask, bool adjoint, LaunchShape& sh);
 
 // Slice width of the slice-major scratch copy this launch should gather from (see repack_slice_major_kernel);
 // 0 = gather from the source as it is.  Because every slice width >= 64 produces the same summation tree, the copy
@@ -273,14 +388,26 @@ size_t scratch_bytes(const LaunchShape& sh, int rs) {
 }
 
 struct Schedule {
-    bool pipe, scalar128, exact, shortrow;
+    bool pipe, scalar128, exact, shortrow, lists, fb4;
     int slice;
 };
 
 // The launch-time decisions (also reported by h2gcn_plan_schedule).  `exact_ok`: the float4 kernels can serve the
 // launch (d >= 4; narrower rows take the generic column-tiled kernel).
+//
+// CSR-adaptive dispatch.  Long segments (>= long_row_threshold) always have their own workgroups.  For the rest:
+//   * segments short throughout (mean < 16 nonzeros over the selected hops): the IN-TILE short-row mode -- tile walk, G
+//     consecutive short rows per round, one lane group each (the fastest walk on such operands: lowdeg 7.0 vs 7.5-8.1 ms
+//     list-driven, hbm16m 24.1 vs 25.3-27.9, profiles/r04_ab_short_walks.txt);
+//   * MIXED launches (mean >= 16, but at least `short_min_frac` of the segments are short: a sparse hop next to a dense
+//     one -- the reference's 1-hop / 2-hop rings --, short rows scattered among longer ones): LIST-DRIVEN by segment
+//     class -- short segments from the plan's binned list, one lane group each, wherever they sit; medium ones one wave
+//     each; no tile walk (bimodal shape, a third of the edges in short segments: 27.7 vs 29.6-30.3 ms on the wave walk,
+//     28.9-29.2 in-tile; neutral where the longer segments carry the bytes: h2gcn_like, products_tail);
+//   * otherwise the wave-per-segment tile walk.
+// (Rounds 2-3 chose ONE walk per launch from the pooled mean alone.)
 Schedule decide(int variant, bool exact_ok, int d, int rows_per_wave, int n_sel, int forced_slice, int64_t n_src_rows,
-                double avg_segment_nnz, bool rows_line_aligned = false) {
+                double avg_segment_nnz, bool rows_line_aligned, bool gen, double short_frac, double short_nnz_frac, double short_min_frac) {
     Schedule sc;
     // index prefetch across segments: pays on short segments (+4 % at mean degree 4), costs ~0.4 % on long ones;
     // variant 2 forces it, variant 3 forbids it (bitwise-identical results either way)
@@ -289,45 +416,92 @@ Schedule decide(int variant, bool exact_ok, int d, int rows_per_wave, int n_sel,
     sc.scalar128 = exact_ok && variant == 1 && d == 128 && forced_slice == 0;  // variant 1 only exists for d = 128
     sc.slice = (exact_ok && !sc.scalar128) ? pick_slice_cols(d, n_src_rows, forced_slice, avg_segment_nnz, rows_line_aligned) : 0;
     sc.exact = sc.slice > 0 || sc.scalar128;
-    // short segments: one lane group per segment (G segments of a wave in flight at once) -- slices of 64 / 128 columns;
-    // variant 5 forces it, variants 2 / 3 keep the wave-per-segment walk with / without the index prefetch
-    sc.shortrow = (variant == 5 || (variant == 0 && avg_segment_nnz < 16.0)) && sc.exact && !sc.scalar128 &&
-                  (sc.slice == 64 || sc.slice == 128);
-    sc.pipe = sc.pipe && sc.exact && !sc.shortrow;
+    const bool grouped_ok = sc.exact && !sc.scalar128 && !gen && (sc.slice == 64 || sc.slice == 128);   // 4 / 2 lane groups, plain stores
+    // variant 5 forces the in-tile short-row mode, variant 6 the list-driven launch (when a short segment exists at all);
+    // variants 2 / 3 keep the wave-per-segment walk with / without the index prefetch
+    sc.shortrow = grouped_ok && (variant == 5 || (variant == 0 && avg_segment_nnz < 16.0));
+    sc.lists = grouped_ok && !sc.shortrow && short_frac > 0.0 && (variant == 6 || (variant == 0 && short_frac >= short_min_frac));
+    sc.pipe = sc.pipe && sc.exact && !sc.shortrow && !sc.lists && !gen;
+    // shallow load batches (more waves per SIMD) once the gather source is far beyond the caches: in-tile mode always
+    // (profiles/r02_ab_short_row_occupancy_auto.txt), list-driven launches when most nonzeros sit in short segments
+    const bool beyond = (double)n_src_rows * d * 4.0 >= 512.0 * 1024 * 1024;
+    sc.fb4 = beyond && (sc.shortrow || (sc.lists && short_nnz_frac > 0.5));
     return sc;
 }
 
 template <bool SUM>
-int launch(LaunchParams& p, int variant, bool off32, int forced_slice, int64_t n_src_rows, double avg_segment_nnz,
-           bool rows_line_aligned, hipStream_t stream) {
+int launch(LaunchParams& p, const h2gcn_plan* plan, const LaunchShape& sh, bool off32, int forced_slice, hipStream_t stream) {
     using namespace h2gcn;
+    // A/B measurements only (profiles/r04_ab_off64_*.txt): run the 64-bit-offset instantiations on an operand that would
+    // qualify for 32-bit gather offsets
+    static const bool force_off64 = getenv("H2GCN_FORCE_OFF64") != nullptr;
+    if (force_off64) off32 = false;
+    const int variant = plan->variant;
     const bool exact_ok = p.d >= 4;
-    const Schedule sc = decide(variant, exact_ok, p.d, p.rows_per_wave, p.n_sel, forced_slice, n_src_rows, avg_segment_nnz,
-                               rows_line_aligned);
     // general store (bias / ReLU epilogue, element-wise tail of a width that is not a multiple of 4): dedicated instantiations
     const bool gen = p.d % 4 != 0 || p.bias != nullptr || p.relu != 0 || p.accumulate != 0;
-    // short-row kernels: shallow fallback batches (more waves per SIMD) once the gather source is far beyond the caches
-    const bool short_fb4 = (double)n_src_rows * p.d * 4.0 >= 512.0 * 1024 * 1024;
-    const bool pipe = sc.pipe && !gen, scalar128 = sc.scalar128, exact = sc.exact, shortrow = sc.shortrow && !gen;
+    const Schedule sc = decide(variant, exact_ok, p.d, p.rows_per_wave, p.n_sel, forced_slice, sh.n_src, sh.avg,
+                               sh.src_line_aligned, gen, sh.short_frac, sh.short_nnz_frac, plan->short_min_frac);
+    const bool short_fb4 = sc.fb4;
+    const bool pipe = sc.pipe, scalar128 = sc.scalar128, exact = sc.exact, shortrow = sc.shortrow, lists = sc.lists;
     const int slice = sc.slice;
     p.slice_cols = exact ? (slice > 0 ? slice : 128) : p.d;
     p.n_slices = exact ? (p.d + p.slice_cols - 1) / p.slice_cols : 1;
     if (p.src_slice_stride == 0) p.src_slice_stride = p.slice_cols;  // row-major source
-    p.blocks_per_slice = (int64_t)p.n_long + p.tiles_per_xcd * kNumXcd;
+    p.short_max = -1;
+    p.short_groups = p.med_groups = 0;
+    if (lists) {
+        // list-driven launch: short-list workgroups serve 4 waves x 64 entries, medium-list workgroups 4 waves x
+        // med_per_wave entries; forward -- one run of workgroups per selected hop and class
+        p.med_per_wave = SUM ? std::max(1, std::min(p.rows_per_wave, kWave / p.n_sel)) : std::min(2 * p.rows_per_wave, 16);
+        static const int env_mpw = getenv("H2GCN_MED_PER_WAVE") ? atoi(getenv("H2GCN_MED_PER_WAVE")) : 0;
+        if (env_mpw >= 1 && env_mpw * p.n_sel <= kWave) p.med_per_wave = env_mpw;
+        int64_t sblocks = 0, mblocks = 0, n_listed = 0, longest = 0;
+        for (int s = 0; s < sh.n_short_lists; ++s) {
+            n_listed += sh.short_count[s];
+            longest = std::max(longest, sh.short_count[s]);
+        }
+        // entries per lane-group wave: 64 (one coalesced list read, 16-32 rounds per wave) on big operands; fewer on
+        // small ones, so that the launch still has several waves per SIMD slot of the chip (arxiv shape: 0.3M entries)
+        static const int env_spw = getenv("H2GCN_SHORT_PER_WAVE") ? atoi(getenv("H2GCN_SHORT_PER_WAVE")) : 0;
+        static const int env_major = getenv("H2GCN_SHORT_HOP_MAJOR") ? atoi(getenv("H2GCN_SHORT_HOP_MAJOR")) : -1;
+        p.short_per_wave = n_listed >= (int64_t)64 * 8 * 256 * 28 ? 64 : (n_listed >= (int64_t)32 * 8 * 256 * 28 ? 32 : 16);
+        if (env_spw >= 4 && env_spw <= 64 && env_spw % 4 == 0) p.short_per_wave = env_spw;
+        p.short_hop_major = env_major >= 0 ? env_major : 0;
+        const int64_t s_per_block = (int64_t)kWavesPerBlock * p.short_per_wave;
+        for (int s = 0; s < sh.n_short_lists; ++s) {
+            p.short_list[s] = sh.short_list[s];
+            p.short_count[s] = sh.short_count[s];
+            sblocks += (sh.short_count[s] + s_per_block - 1) / s_per_block;
+            p.short_end[s] = sblocks;
+            p.med_list[s] = sh.med_list[s];
+            p.med_count[s] = sh.med_count[s];
+            const int64_t per_block = (int64_t)kWavesPerBlock * p.med_per_wave;
+            mblocks += (sh.med_count[s] + per_block - 1) / per_block;
+            p.med_end[s] = mblocks;
+        }
+        if (!SUM && !p.short_hop_major) sblocks = (longest + s_per_block - 1) / s_per_block * sh.n_short_lists;   // chunk-major: every hop padded to the longest list
+        p.short_groups = (sblocks + kNumXcd - 1) / kNumXcd;
+        p.med_groups = (mblocks + kNumXcd - 1) / kNumXcd;
+        p.short_max = plan->short_max;
+        p.blocks_per_slice = (int64_t)p.n_long + (p.short_groups + p.med_groups) * kNumXcd;
+    } else {
+        p.blocks_per_slice = (int64_t)p.n_long + p.tiles_per_xcd * kNumXcd;
+    }
     const int64_t n_blocks = p.blocks_per_slice * p.n_slices;
     if (n_blocks <= 0) return H2GCN_OK;
     if (n_blocks > 0x7fffffffLL) return fail(H2GCN_ERR_INVALID_ARGUMENT, "grid too large (%lld blocks)", (long long)n_blocks);
     const dim3 grid((unsigned)n_blocks), block(kBlock);
-#define H2GCN_LAUNCH_SHORT(VEC, LPR)                                                                                              \
+#define H2GCN_LAUNCH_LISTS(VEC, LPR)                                                                                              \
     do {                                                                                                                          \
         if (off32 && short_fb4)                                                                                                   \
-            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, true, false, true, false, 4>), grid, block, 0, stream, p);   \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, true, false, false, false, 4, true>), grid, block, 0, stream, p);   \
         else if (off32)                                                                                                           \
-            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, true, false, true, false, 8>), grid, block, 0, stream, p);   \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, true, false, false, false, 8, true>), grid, block, 0, stream, p);   \
         else if (short_fb4)                                                                                                       \
-            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, false, false, true, false, 4>), grid, block, 0, stream, p);  \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, false, false, false, false, 4, true>), grid, block, 0, stream, p);  \
         else                                                                                                                      \
-            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, false, false, true, false, 8>), grid, block, 0, stream, p);  \
+            hipLaunchKernelGGL((spmm_hops_kernel<VEC, LPR, true, SUM, false, false, false, false, 8, true>), grid, block, 0, stream, p);  \
     } while (0)
 #define H2GCN_LAUNCH(VEC, LPR, EXACT)                                                                             \
     do {                                                                                                          \
@@ -348,10 +522,14 @@ int launch(LaunchParams& p, int variant, bool off32, int forced_slice, int64_t n
         H2GCN_LAUNCH(2, 64, true);  // one neighbour per load instruction, scalar base addressing
     } else if (slice == 256) {
         H2GCN_LAUNCH(4, 64, true);
-    } else if (slice == 128 && shortrow) {
-        H2GCN_LAUNCH_SHORT(4, 32);
-    } else if (slice == 64 && shortrow) {
-        H2GCN_LAUNCH_SHORT(4, 16);
+    } else if (slice == 128 && lists) {
+        H2GCN_LAUNCH_LISTS(4, 32);
+    } else if (slice == 64 && lists) {
+        H2GCN_LAUNCH_LISTS(4, 16);
+    } else if ((slice == 128 || slice == 64) && shortrow) {
+        // the in-tile short-row kernels live in a translation unit of their own (spmm_short.hip): compiled next to them,
+        // the tile-walk kernels of THIS file come out 2-6 VGPRs heavier and several of them spill (tools/kernel_resources.py)
+        launch_in_tile_short(SUM, p, slice, off32, short_fb4, grid, stream);
     } else if (slice == 128) {
         H2GCN_LAUNCH(4, 32, true);
     } else if (slice == 64) {
@@ -360,7 +538,7 @@ int launch(LaunchParams& p, int variant, bool off32, int forced_slice, int64_t n
         H2GCN_LAUNCH(1, 64, false);  // d < 4: generic column-tiled path
     }
 #undef H2GCN_LAUNCH
-#undef H2GCN_LAUNCH_SHORT
+#undef H2GCN_LAUNCH_LISTS
     H2GCN_HIP_TRY(hipGetLastError());
     return H2GCN_OK;
 }
@@ -454,6 +632,9 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
         while ((plan->rows_per_wave + 1) * n_hops > h2gcn::kWave && plan->rows_per_wave > 1) plan->rows_per_wave--;
         plan->variant = o.variant;
         plan->slice_cols = o.slice_cols;
+        // segment classes: short <= short_max < medium < long_threshold <= long
+        plan->short_max = std::min(h2gcn::kShortMax, plan->long_threshold - 1);
+        if (const char* e = getenv("H2GCN_SHORT_MIN_FRAC")) plan->short_min_frac = atof(e);   // A/B measurements
         H2GCN_HIP_TRY(hipGetDevice(&plan->device));
         plan->fwd.resize(n_hops);
 
@@ -478,6 +659,7 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
             op.nnz = h_rowptr[k][n_rows];
             if (op.nnz > 0 && (!op.colidx || !op.vals)) return fail(H2GCN_ERR_INVALID_ARGUMENT, "hop %d: colidx/vals is NULL", k);
             collect_long_rows(h_rowptr[k], n_rows, plan->long_threshold, op.long_rows);
+            collect_segment_lengths(h_rowptr[k], n_rows, plan->short_max, plan->long_threshold, op);
             if (!(o.flags & H2GCN_PLAN_SKIP_VALIDATION) && op.nnz > 0) {
                 const int64_t want = (op.nnz + 255) / 256;
                 const unsigned blocks = (unsigned)std::min<int64_t>(want, 4096);
@@ -554,6 +736,7 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
                 op.nnz = nnz;
                 op.perm = t_perm;
                 collect_long_rows(t_rowptr, n_cols, plan->long_threshold, op.long_rows);
+                collect_segment_lengths(t_rowptr, n_cols, plan->short_max, plan->long_threshold, op);
             }
             plan->has_transpose = true;
         }
@@ -566,6 +749,13 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
             int st = get_long_list(plan.get(), false, all, &unused_p, &unused_n);
             if (st == H2GCN_OK && plan->has_transpose) st = get_long_list(plan.get(), true, all, &unused_p, &unused_n);
             if (st != H2GCN_OK) return st;
+            // ... and the binned short segments of that selection (every forward hop's list; the all-hops adjoint list)
+            LaunchShape sh_f = shape_of(plan.get(), all, false);
+            if ((st = fill_short(plan.get(), all, false, sh_f)) != H2GCN_OK) return st;
+            if (plan->has_transpose) {
+                LaunchShape sh_a = shape_of(plan.get(), all, true);
+                if ((st = fill_short(plan.get(), all, true, sh_a)) != H2GCN_OK) return st;
+            }
         }
         *out_plan = plan.release();
         return H2GCN_OK;
@@ -628,6 +818,49 @@ LaunchShape shape_of(const h2gcn_plan* plan, uint32_t mask, bool adjoint) {
     return sh;
 }
 
+// The binned short segments this hop selection can use (lists are built on first use and cached in the plan).
+int fill_short(const h2gcn_plan* plan, uint32_t mask, bool adjoint, LaunchShape& sh) {
+    sh.n_short_lists = 0;
+    sh.short_frac = sh.short_nnz_frac = 0.0;
+    if (plan->short_max < 0 || sh.n_out <= 0 || sh.n_sel <= 0) return H2GCN_OK;
+    int64_t n = 0, nnz = 0;
+    const ClassLists* cl = nullptr;
+    if (!adjoint) {
+        int s = 0;
+        for (int k = 0; k < plan->n_hops; ++k) {
+            if (!(mask & (1u << k))) continue;
+            int st = get_class_lists(plan, false, k, 0, &cl);
+            if (st != H2GCN_OK) return st;
+            if (!cl) return H2GCN_OK;
+            sh.short_list[s] = (const int32_t*)cl->short_dev.p;
+            sh.short_count[s] = cl->n_short;
+            sh.med_list[s] = (const int32_t*)cl->med_dev.p;
+            sh.med_count[s] = cl->n_med;
+            n += cl->n_short;
+            nnz += cl->nnz_short;
+            ++s;
+        }
+        sh.n_short_lists = s;
+        sh.short_frac = (double)n / ((double)sh.n_out * sh.n_sel);
+    } else {
+        if (sh.n_sel > h2gcn::kShortSumHops) return H2GCN_OK;
+        int st = get_class_lists(plan, true, 0, mask, &cl);
+        if (st != H2GCN_OK) return st;
+        if (!cl) return H2GCN_OK;
+        sh.short_list[0] = (const int32_t*)cl->short_dev.p;
+        sh.short_count[0] = cl->n_short;
+        sh.med_list[0] = (const int32_t*)cl->med_dev.p;
+        sh.med_count[0] = cl->n_med;
+        n = cl->n_short;
+        nnz = cl->nnz_short;
+        sh.n_short_lists = 1;
+        sh.short_frac = (double)n / (double)sh.n_out;
+    }
+    if (n == 0) sh.n_short_lists = 0;
+    sh.short_nnz_frac = sh.nnz_sel > 0 ? (double)nnz / (double)sh.nnz_sel : (n > 0 ? 1.0 : 0.0);
+    return H2GCN_OK;
+}
+
 }  // namespace
 
 int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, int64_t ld_src, int32_t d,
@@ -639,17 +872,62 @@ int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint
     if (d < 1 || ld_src < d) return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad width %d / stride %lld", d, (long long)ld_src);
     if (adjoint && !plan->has_transpose) return fail(H2GCN_ERR_NO_TRANSPOSE, "plan was created without H2GCN_PLAN_BUILD_TRANSPOSE");
     LaunchShape sh = shape_of(plan, mask, adjoint != 0);
+    if ((st = fill_short(plan, mask, adjoint != 0, sh)) != H2GCN_OK) return st;
     sh.ld_src = ld_src;
     sh.d = d;
     sh.src_line_aligned = (ld_src * 4) % 128 == 0 && (!adjoint || sh.n_sel <= 1 || (d * 4) % 128 == 0);  // aligned base assumed
     const int rs = scratch_slice_cols(plan, sh);
     const Schedule sc = decide(plan->variant, d >= 4, d, plan->rows_per_wave, sh.n_sel, rs > 0 ? rs : plan->slice_cols, sh.n_src, sh.avg,
-                               rs > 0 || sh.src_line_aligned);
+                               rs > 0 || sh.src_line_aligned, d % 4 != 0, sh.short_frac, sh.short_nnz_frac, plan->short_min_frac);
     const int w = sc.exact ? (sc.slice > 0 ? sc.slice : 128) : d;
     if (slice_cols) *slice_cols = w;
     if (n_slices) *n_slices = sc.exact ? (d + w - 1) / w : 1;
-    if (segment_walk) *segment_walk = sc.pipe ? 1 : (sc.shortrow ? 2 : 0);
+    if (segment_walk) *segment_walk = sc.pipe ? 1 : (sc.shortrow ? 2 : (sc.lists ? 3 : 0));
     if (scratch_copy) *scratch_copy = rs > 0 ? 1 : 0;
+    return H2GCN_OK;
+}
+
+int h2gcn_plan_segment_classes(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, int64_t ld_src, int32_t d,
+                               int64_t* segments, int64_t* nonzeros, int64_t* listed) {
+    if (!plan) return fail(H2GCN_ERR_INVALID_ARGUMENT, "plan is NULL");
+    uint32_t mask;
+    int st = resolve_mask(plan, hop_mask, &mask);
+    if (st != H2GCN_OK) return st;
+    if (d < 1 || ld_src < d) return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad width %d / stride %lld", d, (long long)ld_src);
+    if (adjoint && !plan->has_transpose) return fail(H2GCN_ERR_NO_TRANSPOSE, "plan was created without H2GCN_PLAN_BUILD_TRANSPOSE");
+    const std::vector<HopOperand>& ops = adjoint ? plan->adj : plan->fwd;
+    const int64_t n_out = adjoint ? plan->n_cols : plan->n_rows;
+    int s = 0;
+    for (int k = 0; k < plan->n_hops; ++k) {
+        if (!(mask & (1u << k))) continue;
+        const HopOperand& op = ops[k];
+        const int64_t n_long = (int64_t)op.long_rows.size();
+        if (segments) {
+            segments[3 * s + 0] = op.n_short;
+            segments[3 * s + 1] = n_out - op.n_short - n_long;
+            segments[3 * s + 2] = n_long;
+        }
+        if (nonzeros) {
+            nonzeros[3 * s + 0] = op.nnz_short;
+            nonzeros[3 * s + 1] = op.nnz - op.nnz_short - op.nnz_long;
+            nonzeros[3 * s + 2] = op.nnz_long;
+        }
+        ++s;
+    }
+    if (listed) {
+        LaunchShape sh = shape_of(plan, mask, adjoint != 0);
+        if ((st = fill_short(plan, mask, adjoint != 0, sh)) != H2GCN_OK) return st;
+        sh.ld_src = ld_src;
+        sh.d = d;
+        sh.src_line_aligned = (ld_src * 4) % 128 == 0 && (!adjoint || sh.n_sel <= 1 || (d * 4) % 128 == 0);
+        const int rs = scratch_slice_cols(plan, sh);
+        const Schedule sc = decide(plan->variant, d >= 4, d, plan->rows_per_wave, sh.n_sel, rs > 0 ? rs : plan->slice_cols, sh.n_src, sh.avg,
+                                   rs > 0 || sh.src_line_aligned, d % 4 != 0, sh.short_frac, sh.short_nnz_frac, plan->short_min_frac);
+        *listed = 0;
+        if (sc.lists)
+            for (int q = 0; q < sh.n_short_lists; ++q) *listed += sh.short_count[q];
+        if (sc.shortrow) *listed = -1;   // in-tile short-row mode: every round of G consecutive short rows is grouped, no list
+    }
     return H2GCN_OK;
 }
 
@@ -745,7 +1023,8 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
             H2GCN_HIP_TRY(hipGetLastError());
             forced_slice = rs;
         }
-        return launch<false>(p, plan->variant, off32, forced_slice, plan->n_cols, sh.avg, sh.src_line_aligned, (hipStream_t)stream_v);
+        if ((st = fill_short(plan, mask, false, sh)) != H2GCN_OK) return st;
+        return launch<false>(p, plan, sh, off32, forced_slice, (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_opts_f32");
     }
@@ -817,7 +1096,8 @@ int h2gcn_spmm_hops_T_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, cons
             H2GCN_HIP_TRY(hipGetLastError());
             forced_slice = rs;
         }
-        return launch<true>(p, plan->variant, off32, forced_slice, plan->n_rows, sh.avg, sh.src_line_aligned, (hipStream_t)stream_v);
+        if ((st = fill_short(plan, mask, true, sh)) != H2GCN_OK) return st;
+        return launch<true>(p, plan, sh, off32, forced_slice, (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_T_f32");
     }

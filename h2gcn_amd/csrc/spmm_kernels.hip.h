@@ -17,6 +17,11 @@
 //     (no LDS round trip), then LPR lanes write the output row with 16-byte non-temporal stores;
 //   * (row,hop) segments with >= long_row_threshold nonzeros are taken out of the regular path and split
 //     over the 4 waves of a workgroup: LDS-staged partial sums, summed in fixed wave order (deterministic);
+//   * CSR-adaptive by SEGMENT CLASS: the plan bins every segment as short (<= 16 nonzeros) / medium / long.  A launch whose
+//     segments are short throughout keeps the tile walk with G consecutive short rows per round (in-tile short-row mode);
+//     a MIXED launch (mean >= 16 but >= 5 % of the segments short: a sparse hop next to a dense one, short rows scattered
+//     among long ones) is list-driven -- each class has its own walk (one lane group / one wave / one workgroup per
+//     segment, see short_list_blocks), wherever the short segments sit;
 //   * the block -> row-tile map gives every XCD (private L2) a contiguous range of rows.
 //
 // Floating point: fp32 multiply-add per nonzero, ONE CANONICAL SUMMATION TREE per output element:
@@ -55,11 +60,13 @@ constexpr int kMaxRowsPerWave = 7;  // (rows_per_wave + 1) * n_hops row pointers
 constexpr int kMinWavesPerSimd = H2GCN_MIN_WAVES;
 #ifndef H2GCN_SHORT_MIN_WAVES
 #define H2GCN_SHORT_MIN_WAVES 4
-#endif  // __launch_bounds__ of the fast paths (waves per SIMD the register budget must allow)
+#endif  // __launch_bounds__ of the in-tile short-row kernels (waves per SIMD the register budget must allow)
 #ifndef H2GCN_SHORT_FB4_MIN_WAVES
 #define H2GCN_SHORT_FB4_MIN_WAVES 7
-#endif  // ... of the forward short-row kernels with shallow fallback batches (memory-resident operands: occupancy buys
-        // bandwidth; fits without spilling -- the adjoint ones would spill and stay at 6)
+#endif  // ... of the forward in-tile short-row kernels with shallow fallback batches and of the list-driven kernels with
+        // shallow load batches (FB = 4; memory-resident operands whose nonzeros sit mostly in short segments: occupancy
+        // buys bandwidth -- even at the price of 12 B of scratch in the one instantiation that needs 78 registers, the
+        // forward 128-column kernel with 64-bit offsets: lowdeg 6.97 ms at 7 waves vs 7.21 at 6 without scratch)
 #ifndef H2GCN_MAIN_MAXB
 #define H2GCN_MAIN_MAXB 8
 #endif  // deepest load batch of the bandwidth kernels (8 x 16 B per lane in flight)
@@ -69,6 +76,18 @@ constexpr int kMinWavesPerSimd = H2GCN_MIN_WAVES;
 #ifndef H2GCN_WIDE_MIN_WAVES
 #define H2GCN_WIDE_MIN_WAVES H2GCN_MIN_WAVES
 #endif  // ... of the 128 / 256-column slices, whose lanes keep 2 / 4 partials of the canonical tree
+constexpr int kShortMax = 16;       // longest segment of the binned short class (one index fetch per lane group of 16 lanes)
+constexpr int kShortSumHops = 4;    // SUM mode serves listed rows only for selections of at most this many hops (LDS staging)
+#ifndef H2GCN_SHORT_PREFETCH
+#define H2GCN_SHORT_PREFETCH 2
+#endif  // index fetches the list walk keeps in flight ahead of the round that is gathering
+#ifndef H2GCN_OFF64_HEAVY_MIN_WAVES
+#define H2GCN_OFF64_HEAVY_MIN_WAVES 5
+#endif  // ... of the 64-bit-offset kernels with a general store or a 128 / 256-column slice (two address VGPRs per load in
+        // flight): 82-88 VGPRs at 5 waves per SIMD; pinned to 6 they sit on the 80-register cap with 12-28 bytes of scratch.
+        // Same-box A/B (profiles/r04_ab_off64_launch_bounds.txt): 5 waves without scratch is level with or 0.1-0.5 % ahead of 6
+        // waves with it (slice 128, forced 64-bit offsets: 19.74-19.80 vs 19.84-19.85 ms; training step at hidden 100: 115.0 vs
+        // 115.4-119.0 ms) -- and the 64-bit kernels cost nothing over the 32-bit ones on the same operand (17.63 vs 17.63 ms)
 constexpr int kMaxTileCols = 256;   // columns one pass of a wave covers at most (64 lanes x float4)
 constexpr int kTreeParts = 4;       // partials of the canonical summation tree (see the header comment)
 
@@ -113,6 +132,24 @@ struct LaunchParams {
     const float* bias;         // optional epilogue: dst = act(sum + bias[col]); NULL = none
     int relu;                  // optional epilogue: act = max(., 0)
     int accumulate;            // general-store kernels: dst += sum instead of dst = sum (adjoint into an existing gradient)
+    // binned SHORT segments (SHORT kernels; see short_list_blocks): segments of at most short_max nonzeros are taken out of
+    // the tile walk and served from plan-owned lists, one lane group per segment
+    const int32_t* short_list[H2GCN_MAX_HOPS];  // forward: rows whose segment of selected hop s is short, ascending;
+                                                // SUM: [0] = rows whose segments of ALL selected hops are short
+    int64_t short_count[H2GCN_MAX_HOPS];        // entries of each list
+    int64_t short_end[H2GCN_MAX_HOPS];          // forward: running number of list workgroups up to and including hop s
+    int64_t short_groups;                       // groups of 8 short-list workgroups, interleaved with the medium-list groups
+    int short_max;                              // -1: no lists (the tile walk serves every segment below long_threshold)
+    int short_per_wave;                         // list entries one wave serves (<= 64, a multiple of 4)
+    int short_hop_major;                        // forward: 1 = all workgroups of hop 0's list, then hop 1's ...; 0 = workgroup b
+                                                // serves chunk b / n_sel of hop b % n_sel (a row's hop outputs close in time)
+    // ... and the MEDIUM segments (everything between short and long) of such a launch: same layout, walked one wave per
+    // segment, med_per_wave consecutive entries per wave (see medium_list_blocks); SHORT kernels have no tile walk at all
+    const int32_t* med_list[H2GCN_MAX_HOPS];
+    int64_t med_count[H2GCN_MAX_HOPS];
+    int64_t med_end[H2GCN_MAX_HOPS];
+    int64_t med_groups;
+    int med_per_wave;
 };
 
 template <int VEC>
@@ -373,14 +410,10 @@ __device__ __forceinline__ void accumulate_segment_prefetched(const int32_t* __r
     }
 }
 
-// ---- short-row mode ("one lane group per segment") ------------------------------------------------------------
-// When segments are short (a handful of nonzeros: 1-hop matrices of citation-like graphs, mean degree 4-8), giving
-// a whole wave to one segment leaves the kernel latency-bound: one segment = one dependent chain index -> gather ->
-// fold -> store with a single 1 KiB load in flight.  Here the G lane groups of a wave take G DIFFERENT segments
-// (same hop, G consecutive rows) and walk them in lock step: G segments' gathers are in flight together and no
-// cross-lane fold is needed.  The arithmetic is the canonical tree of the header comment: a group keeps the four
-// partials P[j mod 4] in registers and combines them as (P0 + P1) + (P2 + P3) -- so which mode served a row can never
-// be seen in the result (row partitions, rows_per_wave and tile geometry stay invisible).
+// ---- one lane group per segment: the inner loop of the short class (see short_list_blocks below) ---------------------
+// The G lane groups of a wave hold G DIFFERENT short segments and walk them in lock step: G segments' gathers are in
+// flight together and no cross-lane fold is needed.  The arithmetic is the canonical tree of the header comment: a group
+// keeps the four partials P[j mod 4] in registers and combines them as (P0 + P1) + (P2 + P3).
 // Handles segments of at most LPR nonzeros (one index fetch per group): `c`, `v` hold the group's indices/values
 // lane-wise (lane li of the group = neighbour li), `n_mine` its length, `n_max` the longest of the round (uniform).
 template <int VEC, int LPR, bool OFF32>
@@ -437,7 +470,11 @@ __device__ __forceinline__ void store_vec(float* p, const float (&acc)[VEC]) {
         typename VecT<VEC>::type o;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) o[i] = acc[i];
+#ifdef H2GCN_PLAIN_STORES   // A/B builds only (profiles/r04_ab_output_stores.txt)
+        *reinterpret_cast<typename VecT<VEC>::type*>(p) = o;
+#else
         __builtin_nontemporal_store(o, reinterpret_cast<typename VecT<VEC>::type*>(p));
+#endif
     }
 }
 
@@ -482,128 +519,205 @@ __device__ __forceinline__ void store_out(const P& p, float* row, int col0, int 
     }
 }
 
-// VEC    floats per lane per gathered row (4 on the fast paths)
-// LPR    lanes that cover one gathered row
-// EXACT  the launch covers the feature columns in n_slices = ceil(d / (VEC*LPR)) slices of VEC*LPR columns,
-//        slice-major (all row tiles of slice 0, then slice 1, ...: while a slice is being processed the gather
-//        working set is n_cols * slice_cols * 4 bytes, which is what the 256 MiB Infinity Cache sees).  A last
-//        slice that sticks out beyond the source's valid columns costs no predication: the lanes beyond re-read the
-//        last valid float4 of the row (same cache line, no extra traffic) and simply do not store.  Otherwise (!EXACT)
-//        LPR == 64 and each wave loops over masked column tiles (any d, any alignment)
-// SUM    adjoint mode: one output row = sum over the selected hops
-// OFF32  32-bit gather offsets (see GatherAddr)
-// SHORT  short-row mode (see accumulate_grouped): rounds of G segments whose lengths are all <= LPR are served one
-//        lane group per segment; other rounds fall back to the wave-per-segment walk.  Same bits either way.
-// EPI    general store (see store_out): optional bias / ReLU epilogue, element-wise bounded stores for odd widths and
-//        unaligned outputs (separate instantiations: the extra registers would otherwise push the 6-waves-per-SIMD
-//        variants of the plain aggregation into spilling)
-// FB     (short-row kernels) deepest load batch of the wave-per-segment fallback: 4 keeps the kernel at 7 waves per SIMD
-//        (memory-resident operands: occupancy buys bandwidth), 8 at 5 (cache-resident operands: the longer segments'
-//        loads in flight matter more)
-template <int VEC, int LPR, bool EXACT, bool SUM, bool OFF32, bool PIPE = false, bool SHORT = false, bool EPI = false, int FB = 8>
-__global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? (FB == 4 && !SUM ? H2GCN_SHORT_FB4_MIN_WAVES : H2GCN_SHORT_MIN_WAVES) : (LPR >= 32 ? H2GCN_WIDE_MIN_WAVES : kMinWavesPerSimd)) : 2) void spmm_hops_kernel(const LaunchParams p) {
-    static_assert(EXACT || LPR == kWave, "column-tiled path uses the whole wave per row");
-    __shared__ float partial[kWavesPerBlock][kMaxTileCols];
+// ---- binned short segments ("lane group per segment" from a plan-owned list) --------------------------------------------
+// CSR-adaptive dispatch by SEGMENT CLASS: the plan bins every (row, hop) segment by its length -- short (<= kShortMax
+// nonzeros), medium, long (>= long_row_threshold) -- and a launch serves each class with the walk that suits it:
+//   long    one workgroup per segment, 4 waves, LDS-staged partial sums            (long_list, as before)
+//   medium  one wave per segment, rows_per_wave consecutive rows per wave          (the tile walk, which skips the others)
+//   short   one LANE GROUP per segment, from the list                              (here)
+// A short segment walked by a whole wave is a dependent chain index -> gather -> fold -> store with a single 1-KiB load in
+// flight; here the G = 64/LPR lane groups of a wave take G different segments in lock step, no cross-lane fold is needed,
+// and the index fetches run H2GCN_SHORT_PREFETCH rounds ahead of the gathers.  Because the list is built from the segment
+// lengths themselves, WHICH rows are short does not matter: short rows scattered among long ones (real degree sequences),
+// a short hop next to a dense one (the reference's exact-1-hop vs exact-2-hop rings, _dataset.py:138-158) -- every short
+// segment is served this way, and every other one by the walk of its own class, in the same launch.
+// One wave serves 64 consecutive list entries: lane e fetches entry e's row id and row pointers (one coalesced list read,
+// one 16-byte row-pointer read per lane and hop) and parks them in LDS; round t hands entries t*G .. t*G+G-1 to the lane
+// groups.  Forward: a list workgroup belongs to one selected hop.  SUM: an entry is a row whose segments of ALL selected
+// hops are short; the partials run on across the hops exactly as the wave walk's accumulators do.
+// The arithmetic is the canonical tree of the header comment (a group keeps P[j mod 4] in registers, combined as
+// (P0 + P1) + (P2 + P3)), so which class served a segment can never be seen in the result.
+template <int VEC, int LPR, bool SUM, bool OFF32, bool EPI, int PD>
+__device__ __forceinline__ void short_list_blocks(const LaunchParams& p, int64_t sblock, int lane, int wave, int64_t lane_off0,
+                                                  int64_t src_col_begin, int lcol, int ecol,
+                                                  uint64_t (&s_seg)[kWavesPerBlock][kShortSumHops][kWave],
+                                                  int32_t (&s_row)[kWavesPerBlock][kWave]) {
+    using off_t = typename std::conditional<OFF32, uint32_t, int64_t>::type;
+    constexpr int G = kWave / LPR;
+    constexpr uint64_t kBeginMask = (1ull << 58) - 1;
+    const int li = lane % LPR, g = lane / LPR;
+    const int n_sel = p.n_sel;
+    int hop = 0;  // forward: the selected hop this workgroup's list belongs to
+    int64_t local = sblock;
+    if constexpr (!SUM) {
+        if (p.short_hop_major) {
+            while (hop + 1 < n_sel && sblock >= p.short_end[hop]) ++hop;
+            if (hop > 0) local -= p.short_end[hop - 1];
+        } else {
+            local = sblock / n_sel;
+            hop = (int)(sblock - local * n_sel);
+        }
+    }
+    const int spw = p.short_per_wave;
+    const int64_t entry0 = (local * kWavesPerBlock + wave) * spw;
+    const int64_t left = p.short_count[hop] - entry0;
+    if (left <= 0) return;
+    const int n_here = left < spw ? (int)left : spw;
+    const int NS = SUM ? n_sel : 1;  // segments per entry
+    if (lane < n_here) {
+        const int32_t row = __builtin_nontemporal_load(p.short_list[hop] + entry0 + lane);
+        s_row[wave][lane] = row;
+        for (int s = 0; s < NS; ++s) {
+            const int64_t* rp = p.hop[SUM ? s : hop].rowptr + row;
+            const int64_t b0 = rp[0], b1 = rp[1];
+            s_seg[wave][s][lane] = (uint64_t)b0 | ((uint64_t)(b1 - b0) << 58);  // length <= kShortMax: 6 bits
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n_rounds = (n_here + G - 1) / G;
+    const int n_steps = n_rounds * NS;  // step i = (round t, segment s), s fastest
+
+    // index fetch of one step for this lane's group: lane li holds neighbour li of the group's segment; len -1 = no entry
+    int cq[PD], lq[PD];
+    float vq[PD];
+    int ft = 0, fs = 0;  // (t, s) of the next step to fetch
+    auto fetch = [&](int& c, float& v, int& len) {
+        c = 0;
+        v = 0.f;
+        len = -1;
+        const int e = ft * G + g;
+        if (e < n_here) {
+            const uint64_t packed = s_seg[wave][fs][e];
+            len = (int)(packed >> 58);
+            if (li < len) {
+                const HopCsr& h = p.hop[SUM ? fs : hop];
+                const int64_t at = (int64_t)(packed & kBeginMask) + li;
+                c = __builtin_nontemporal_load(h.colidx + at);
+                v = __builtin_nontemporal_load(h.vals + at);
+            }
+        }
+        if (++fs == NS) {
+            fs = 0;
+            ++ft;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < PD; ++k) {
+        cq[k] = 0;
+        vq[k] = 0.f;
+        lq[k] = -1;
+        if (k < n_steps) fetch(cq[k], vq[k], lq[k]);
+    }
+    float part[kTreeParts][VEC];
+    int t = 0, s = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        const int c = cq[0], len = lq[0];
+        const float v = vq[0];
+#pragma unroll
+        for (int k = 0; k + 1 < PD; ++k) {
+            cq[k] = cq[k + 1];
+            vq[k] = vq[k + 1];
+            lq[k] = lq[k + 1];
+        }
+        lq[PD - 1] = -1;
+        if (i + PD < n_steps) fetch(cq[PD - 1], vq[PD - 1], lq[PD - 1]);
+        if (s == 0) zero_acc<VEC, kTreeParts>(part);
+        int n_max = 0;
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg) n_max = max(n_max, __builtin_amdgcn_readlane(len, gg * LPR));
+        const int hs = SUM ? s : hop;
+        const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[hs] + src_col_begin - VEC), (off_t)lane_off0,
+                                     (off_t)(p.ld_src * 4)};
+        accumulate_grouped<VEC, LPR, OFF32>(c, v, len, n_max, lane, addr, part);
+        if (s == NS - 1) {
+            if (len >= 0) {
+                float tot[VEC];
+                combine_partials<VEC>(part, tot);
+                const int64_t row = s_row[wave][t * G + g];
+                store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[hop]), lcol, ecol, tot);
+            }
+            s = 0;
+            ++t;
+        } else {
+            ++s;
+        }
+    }
+}
+
+// The MEDIUM class of a list-driven launch: one wave per segment, p.med_per_wave consecutive list entries per wave.
+// Forward: an entry is a (row, hop) segment of the hop the workgroup's list belongs to; SUM: a row that is neither listed
+// as short nor owned by the long path, all selected hops' segments accumulated into one output row.  Lane j*NS + s fetches
+// the row pointers of entry j, hop s; the walk itself is accumulate_segment, i.e. the tile walk's arithmetic.
+template <int VEC, int LPR, bool SUM, bool OFF32, bool EPI, int MAXB>
+__device__ __forceinline__ void medium_list_blocks(const LaunchParams& p, int64_t mblock, int lane, int wave, int64_t lane_off0,
+                                                   int64_t src_col_begin, int lcol, int ecol) {
     using off_t = typename std::conditional<OFF32, uint32_t, int64_t>::type;
     constexpr int NP = Tree<LPR>::NP;
-    constexpr int kMainB = LPR >= 32 ? H2GCN_WIDE_MAXB : H2GCN_MAIN_MAXB;
-
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = wave_uniform(threadIdx.x >> 6);
-    const int li = lane % LPR;  // lane inside its group
     const int g = lane / LPR;
     const int n_sel = p.n_sel;
-
-    // slice-major block order
-    const int64_t bid = blockIdx.x;
-    const int slice = EXACT ? (int)(bid / p.blocks_per_slice) : 0;
-    const int64_t b = EXACT ? bid - (int64_t)slice * p.blocks_per_slice : bid;
-    const int col_begin = EXACT ? slice * (VEC * LPR) : 0;
-    const int col_end = EXACT ? col_begin + VEC * LPR : p.d;
-    const int64_t src_col_begin = EXACT ? (int64_t)slice * p.src_slice_stride : 0;  // where this slice starts in the source
-    // EXACT: this lane's nominal columns are lcol .. lcol+VEC-1.  A lane whose vector would stick out beyond the readable
-    // width of the source row gathers the row's LAST VEC columns instead (ecol = d_src - VEC: same cache line, no extra
-    // traffic, no predication in the gather loop).  For the lane that straddles the end (width not a multiple of VEC) those
-    // columns overlap its left neighbour's and include the ones it owns; lanes entirely beyond the end own nothing.
-    const int lcol = col_begin + li * VEC;
-    const int ecol = EXACT ? ((lcol + VEC <= p.d_src) ? lcol : p.d_src - VEC) : lcol;
-    // byte offset of ecol inside the slice, biased by VEC elements so that it is never negative (the tail of a slice that
-    // holds fewer than VEC columns reaches back into the previous slice); the wave-uniform base is lowered accordingly
-    const off_t lane_off0 = (off_t)((ecol - col_begin + VEC) * 4);
-    constexpr int kBias = EXACT ? VEC : 0;
-
-    if (b < p.n_long) {
-        // ---- long segment: the 4 waves of this workgroup share one (row, hop) [forward] / one row [SUM] ----
-        const int64_t entry = p.long_list[b];
-        const int64_t row = SUM ? entry : (entry >> 4);
-        const int s_first = SUM ? 0 : (int)(entry & 15);
-        const int s_last = SUM ? n_sel : s_first + 1;
-        for (int col0 = col_begin; col0 < col_end; col0 += VEC * LPR) {
-            const bool lane_active = EXACT || (col0 + li * VEC < p.d);
-            float acc[NP][VEC];
-            zero_acc<VEC, NP>(acc);
-            for (int s = s_first; s < s_last; ++s) {
-                const HopCsr& h = p.hop[s];
-                const int64_t sb = h.rowptr[row], se = h.rowptr[row + 1];
-                const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin + (col0 - col_begin) - kBias),
-                                             EXACT ? lane_off0 : (off_t)(li * VEC * 4), (off_t)(p.ld_src * 4)};
-                accumulate_segment<VEC, LPR, !EXACT, OFF32, kMainB>(h.colidx, h.vals, sb, se, wave, kWavesPerBlock, addr, lane,
-                                                            lane_active, acc);
-            }
-            float tot[VEC];
-            fold_tree<VEC, LPR, NP>(acc, tot);
-            if (g == 0) {
-                // this lane's sums belong to columns ecol .. ecol+VEC-1 (tile-relative index below); a tail lane overlaps its
-                // left neighbour with identical values, lanes entirely beyond the row's end contribute nothing
-                const int rel = EXACT ? ecol - col_begin : li * VEC;
-                if (!EXACT || lcol < p.d_src) {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i)
-                        if (rel + i >= 0) partial[wave][rel + i] = tot[i];
-                }
-            }
-            __syncthreads();
-            // fixed-order sum of the 4 wave totals; thread c owns column col0 + c
-            const int c = threadIdx.x;
-            if (c < VEC * LPR && col0 + c < p.d) {
-                float t = partial[0][c];
-#pragma unroll
-                for (int w = 1; w < kWavesPerBlock; ++w) t += partial[w][c];
-                const int64_t off = row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_first]) + col0 + c;
-                if constexpr (EPI) {
-                    if (p.accumulate) t += p.dst[off];
-                    if (p.bias) t += p.bias[col0 + c];
-                    if (p.relu) t = fmaxf(t, 0.f);
-                }
-                __builtin_nontemporal_store(t, p.dst + off);
-            }
-            if (!EXACT) __syncthreads();
-        }
-        return;
+    int hop = 0;
+    int64_t local = mblock;
+    if constexpr (!SUM) {
+        while (hop + 1 < n_sel && mblock >= p.med_end[hop]) ++hop;
+        if (hop > 0) local -= p.med_end[hop - 1];
     }
-
-    // ---- regular path: XCD-aware tile map, each wave walks rows_per_wave consecutive rows ----
-    const int64_t tb = b - p.n_long;
-    const int64_t tile = (tb % kNumXcd) * p.tiles_per_xcd + tb / kNumXcd;
-    if (tile >= p.n_tiles) return;
-    const int rpw = p.rows_per_wave;
-    const int64_t row0 = (tile * kWavesPerBlock + wave) * rpw;
-    if (row0 >= p.n_rows) return;
-    const int64_t rows_here_l = p.n_rows - row0;
-    const int rows_here = rows_here_l < rpw ? (int)rows_here_l : rpw;
-
-    // one wave-wide load fetches every row pointer this wave needs: lane l -> hop l/(rpw+1), row l%(rpw+1)
-    int64_t rp = 0;
+    const int k = p.med_per_wave;
+    const int64_t entry0 = (local * kWavesPerBlock + wave) * k;
+    const int64_t left = p.med_count[hop] - entry0;
+    if (left <= 0) return;
+    const int n_here = left < k ? (int)left : k;
+    const int NS = SUM ? n_sel : 1;
+    int row = 0;
+    int64_t b0 = 0, b1 = 0;
     {
-        const int hs = lane / (rpw + 1), r = lane % (rpw + 1);
-        if (hs < n_sel && r <= rows_here) rp = p.hop[hs].rowptr[row0 + r];
+        const int j = lane / NS, s = lane - j * NS;
+        if (j < n_here) {
+            row = __builtin_nontemporal_load(p.med_list[hop] + entry0 + j);
+            const int64_t* rp = p.hop[SUM ? s : hop].rowptr + row;
+            b0 = rp[0];
+            b1 = rp[1];
+        }
     }
-    const int rp_lo = (int)(rp & 0xffffffff), rp_hi = (int)(rp >> 32);
+    const int b0_lo = (int)(b0 & 0xffffffff), b0_hi = (int)(b0 >> 32), b1_lo = (int)(b1 & 0xffffffff), b1_hi = (int)(b1 >> 32);
+    for (int j = 0; j < n_here; ++j) {
+        const int64_t orow = __builtin_amdgcn_readlane(row, j * NS);
+        float acc[NP][VEC];
+        zero_acc<VEC, NP>(acc);
+        for (int s = 0; s < NS; ++s) {
+            const int l = j * NS + s;
+            const int64_t sb = ((int64_t)__builtin_amdgcn_readlane(b0_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(b0_lo, l);
+            const int64_t se = ((int64_t)__builtin_amdgcn_readlane(b1_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(b1_lo, l);
+            const int hs = SUM ? s : hop;
+            const HopCsr& h = p.hop[hs];
+            const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[hs] + src_col_begin - VEC), (off_t)lane_off0,
+                                         (off_t)(p.ld_src * 4)};
+            accumulate_segment<VEC, LPR, false, OFF32, MAXB>(h.colidx, h.vals, sb, se, 0, 1, addr, lane, true, acc);
+        }
+        float tot[VEC];
+        fold_tree<VEC, LPR, NP>(acc, tot);
+        if (g == 0) store_out<VEC, EPI>(p, p.dst + orow * p.ld_dst + (SUM ? 0 : p.dst_hop_off[hop]), lcol, ecol, tot);
+    }
+}
+
+// ---- in-tile short-row mode (SHORT kernels): the tile walk of a wave whose rows are short ------------------------------
+// Rounds of G consecutive rows (one hop) whose segments are all <= LPR nonzeros are served one lane group per segment
+// (accumulate_grouped), with the next round's index fetch issued before the current round gathers; other rounds fall back to
+// the wave-per-segment walk with load batches of FB.  (Instantiated in spmm_short.hip only -- see there.)
+template <int VEC, int LPR, bool SUM, bool OFF32, bool EPI, int FB>
+__device__ __forceinline__ void in_tile_short_rows(const LaunchParams& p, int lane, int rpw, int64_t row0, int rows_here, int rp_lo, int rp_hi,
+                                                   int64_t lane_off0_, int64_t src_col_begin, int lcol, int ecol) {
+    using off_t = typename std::conditional<OFF32, uint32_t, int64_t>::type;
+    constexpr int NP = Tree<LPR>::NP;
+    constexpr int kBias = VEC;
+    const int li = lane % LPR, g = lane / LPR;
+    const int n_sel = p.n_sel;
+    const off_t lane_off0 = (off_t)lane_off0_;
     auto seg_bound = [&](int l) -> int64_t {
         return ((int64_t)__builtin_amdgcn_readlane(rp_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(rp_lo, l);
     };
-
-    if constexpr (SHORT && EXACT && (kWave / LPR == 2 || kWave / LPR == 4)) {
+    {
         constexpr int G = kWave / LPR;
         const int short_max = min(LPR, p.long_threshold - 1);
         const int n_blocks = (rows_here + G - 1) / G;       // row blocks of G consecutive rows
@@ -751,7 +865,174 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? (FB == 4 && !SUM ? H2GCN_S
         }
         return;
     }
+}
 
+// Instantiations that need more than 80 VGPRs to stay out of scratch (tools/kernel_resources.py): 64-bit gather offsets
+// (two address registers per load in flight) together with a general store, a 128 / 256-column slice or the index prefetch;
+// the prefetching walk on 128-column slices.  They run at H2GCN_OFF64_HEAVY_MIN_WAVES (5) waves per SIMD.
+template <int VEC, int LPR, bool SUM, bool OFF32, bool PIPE, bool SHORT, bool EPI>
+constexpr bool heavy_registers() {
+    if (VEC != 4) return false;
+    if (SHORT) return (SUM && (!OFF32 || LPR >= 32)) || (!OFF32 && LPR >= 32);   // (the list-driven kernels at FB = 8)
+    if (!OFF32) return EPI || LPR >= 32 || PIPE;
+    return PIPE && LPR == 32;
+}
+
+// VEC    floats per lane per gathered row (4 on the fast paths)
+// LPR    lanes that cover one gathered row
+// EXACT  the launch covers the feature columns in n_slices = ceil(d / (VEC*LPR)) slices of VEC*LPR columns,
+//        slice-major (all row tiles of slice 0, then slice 1, ...: while a slice is being processed the gather
+//        working set is n_cols * slice_cols * 4 bytes, which is what the 256 MiB Infinity Cache sees).  A last
+//        slice that sticks out beyond the source's valid columns costs no predication: the lanes beyond re-read the
+//        last valid float4 of the row (same cache line, no extra traffic) and simply do not store.  Otherwise (!EXACT)
+//        LPR == 64 and each wave loops over masked column tiles (any d, any alignment)
+// SUM    adjoint mode: one output row = sum over the selected hops
+// OFF32  32-bit gather offsets (see GatherAddr)
+// SHORT  in-tile short-row mode, for launches whose segments are short throughout (mean < 16 nonzeros): the tile walk, but
+//        rounds of G CONSECUTIVE rows whose segments of one hop are all <= LPR nonzeros are served one lane group per
+//        segment (accumulate_grouped); other rounds fall back to the wave-per-segment walk.  Row pointers stay one coalesced
+//        load per wave and a row's hop outputs leave the same wave -- the fastest walk when every row is short.
+// LISTS  list-driven launch, CSR-adaptive by segment class, for MIXED launches (see short_list_blocks / medium_list_blocks):
+//        the short segments come from the plan's binned list, one lane group per segment wherever they sit; the medium ones
+//        from their list, one wave per segment; the long ones from theirs, one workgroup per segment -- no tile walk.
+//        Same bits as every other walk.
+// EPI    general store (see store_out): optional bias / ReLU epilogue, element-wise bounded stores for odd widths and
+//        unaligned outputs (separate instantiations: the extra registers would otherwise push the 6-waves-per-SIMD
+//        variants of the plain aggregation into spilling)
+// FB     deepest load batch of the wave-per-segment walk inside the SHORT kernels (their fallback) and the LISTS kernels
+//        (medium / long walks): 4 keeps them at 7-8 waves per SIMD (memory-resident operands dominated by short segments:
+//        occupancy buys bandwidth), 8 otherwise (cache-resident operands / launches dominated by longer segments)
+template <int VEC, int LPR, bool EXACT, bool SUM, bool OFF32, bool PIPE = false, bool SHORT = false, bool EPI = false, int FB = 8, bool LISTS = false>
+__global__ __launch_bounds__(kBlock, EXACT ? (LISTS ? (FB == 4 ? H2GCN_SHORT_FB4_MIN_WAVES : heavy_registers<VEC, LPR, SUM, OFF32, PIPE, true, EPI>() ? H2GCN_OFF64_HEAVY_MIN_WAVES : (LPR >= 32 ? H2GCN_WIDE_MIN_WAVES : kMinWavesPerSimd))
+                                                : SHORT ? (FB == 4 && !SUM ? H2GCN_SHORT_FB4_MIN_WAVES : H2GCN_SHORT_MIN_WAVES)
+                                                : heavy_registers<VEC, LPR, SUM, OFF32, PIPE, false, EPI>() ? H2GCN_OFF64_HEAVY_MIN_WAVES
+                                                : (LPR >= 32 ? H2GCN_WIDE_MIN_WAVES : kMinWavesPerSimd)) : 2) void spmm_hops_kernel(const LaunchParams p) {
+    static_assert(!LISTS || (EXACT && !SHORT && !PIPE && (LPR == 16 || LPR == 32)), "list-driven launches exist for 64- and 128-column slices");
+    static_assert(EXACT || LPR == kWave, "column-tiled path uses the whole wave per row");
+    __shared__ float partial[kWavesPerBlock][kMaxTileCols];
+    using off_t = typename std::conditional<OFF32, uint32_t, int64_t>::type;
+    constexpr int NP = Tree<LPR>::NP;
+    constexpr int kMainB = LISTS ? FB : (LPR >= 32 ? H2GCN_WIDE_MAXB : H2GCN_MAIN_MAXB);
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = wave_uniform(threadIdx.x >> 6);
+    const int li = lane % LPR;  // lane inside its group
+    const int g = lane / LPR;
+    const int n_sel = p.n_sel;
+
+    // slice-major block order
+    const int64_t bid = blockIdx.x;
+    const int slice = EXACT ? (int)(bid / p.blocks_per_slice) : 0;
+    const int64_t b = EXACT ? bid - (int64_t)slice * p.blocks_per_slice : bid;
+    const int col_begin = EXACT ? slice * (VEC * LPR) : 0;
+    const int col_end = EXACT ? col_begin + VEC * LPR : p.d;
+    const int64_t src_col_begin = EXACT ? (int64_t)slice * p.src_slice_stride : 0;  // where this slice starts in the source
+    // EXACT: this lane's nominal columns are lcol .. lcol+VEC-1.  A lane whose vector would stick out beyond the readable
+    // width of the source row gathers the row's LAST VEC columns instead (ecol = d_src - VEC: same cache line, no extra
+    // traffic, no predication in the gather loop).  For the lane that straddles the end (width not a multiple of VEC) those
+    // columns overlap its left neighbour's and include the ones it owns; lanes entirely beyond the end own nothing.
+    const int lcol = col_begin + li * VEC;
+    const int ecol = EXACT ? ((lcol + VEC <= p.d_src) ? lcol : p.d_src - VEC) : lcol;
+    // byte offset of ecol inside the slice, biased by VEC elements so that it is never negative (the tail of a slice that
+    // holds fewer than VEC columns reaches back into the previous slice); the wave-uniform base is lowered accordingly
+    const off_t lane_off0 = (off_t)((ecol - col_begin + VEC) * 4);
+    constexpr int kBias = EXACT ? VEC : 0;
+
+    if (b < p.n_long) {
+        // ---- long segment: the 4 waves of this workgroup share one (row, hop) [forward] / one row [SUM] ----
+        const int64_t entry = p.long_list[b];
+        const int64_t row = SUM ? entry : (entry >> 4);
+        const int s_first = SUM ? 0 : (int)(entry & 15);
+        const int s_last = SUM ? n_sel : s_first + 1;
+        for (int col0 = col_begin; col0 < col_end; col0 += VEC * LPR) {
+            const bool lane_active = EXACT || (col0 + li * VEC < p.d);
+            float acc[NP][VEC];
+            zero_acc<VEC, NP>(acc);
+            for (int s = s_first; s < s_last; ++s) {
+                const HopCsr& h = p.hop[s];
+                const int64_t sb = h.rowptr[row], se = h.rowptr[row + 1];
+                const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin + (col0 - col_begin) - kBias),
+                                             EXACT ? lane_off0 : (off_t)(li * VEC * 4), (off_t)(p.ld_src * 4)};
+                accumulate_segment<VEC, LPR, !EXACT, OFF32, kMainB>(h.colidx, h.vals, sb, se, wave, kWavesPerBlock, addr, lane,
+                                                            lane_active, acc);
+            }
+            float tot[VEC];
+            fold_tree<VEC, LPR, NP>(acc, tot);
+            if (g == 0) {
+                // this lane's sums belong to columns ecol .. ecol+VEC-1 (tile-relative index below); a tail lane overlaps its
+                // left neighbour with identical values, lanes entirely beyond the row's end contribute nothing
+                const int rel = EXACT ? ecol - col_begin : li * VEC;
+                if (!EXACT || lcol < p.d_src) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        if (rel + i >= 0) partial[wave][rel + i] = tot[i];
+                }
+            }
+            __syncthreads();
+            // fixed-order sum of the 4 wave totals; thread c owns column col0 + c
+            const int c = threadIdx.x;
+            if (c < VEC * LPR && col0 + c < p.d) {
+                float t = partial[0][c];
+#pragma unroll
+                for (int w = 1; w < kWavesPerBlock; ++w) t += partial[w][c];
+                const int64_t off = row * p.ld_dst + (SUM ? 0 : p.dst_hop_off[s_first]) + col0 + c;
+                if constexpr (EPI) {
+                    if (p.accumulate) t += p.dst[off];
+                    if (p.bias) t += p.bias[col0 + c];
+                    if (p.relu) t = fmaxf(t, 0.f);
+                }
+                __builtin_nontemporal_store(t, p.dst + off);
+            }
+            if (!EXACT) __syncthreads();
+        }
+        return;
+    }
+
+    // ---- regular path: XCD-aware tile map, each wave walks rows_per_wave consecutive rows ----
+    const int64_t tb = b - p.n_long;
+    int64_t tile;
+    if constexpr (LISTS) {
+        // list-driven launch: workgroups come in groups of 8 (one per XCD); short_groups of them serve the binned short
+        // segments and are spread evenly among the med_groups groups that walk the medium ones, so that latency-bound
+        // lane-group waves and bandwidth-bound wave-per-segment waves are resident together.  No tile walk.
+        __shared__ uint64_t s_seg[kWavesPerBlock][kShortSumHops][kWave];
+        __shared__ int32_t s_row[kWavesPerBlock][kWave];
+        const int64_t q = tb >> 3;
+        const int i8 = (int)(tb & 7);
+        const int64_t n_groups = p.short_groups + p.med_groups;
+        const int64_t s_before = (q * p.short_groups) / n_groups;
+        if (((q + 1) * p.short_groups) / n_groups > s_before)
+            short_list_blocks<VEC, LPR, SUM, OFF32, EPI, H2GCN_SHORT_PREFETCH>(p, s_before * kNumXcd + i8, lane, wave, (int64_t)lane_off0,
+                                                                               src_col_begin, lcol, ecol, s_seg, s_row);
+        else
+            medium_list_blocks<VEC, LPR, SUM, OFF32, EPI, FB>(p, (q - s_before) * kNumXcd + i8, lane, wave, (int64_t)lane_off0,
+                                                              src_col_begin, lcol, ecol);
+        return;
+    } else {
+        tile = (tb % kNumXcd) * p.tiles_per_xcd + tb / kNumXcd;
+    }
+    if (tile >= p.n_tiles) return;
+    const int rpw = p.rows_per_wave;
+    const int64_t row0 = (tile * kWavesPerBlock + wave) * rpw;
+    if (row0 >= p.n_rows) return;
+    const int64_t rows_here_l = p.n_rows - row0;
+    const int rows_here = rows_here_l < rpw ? (int)rows_here_l : rpw;
+
+    // one wave-wide load fetches every row pointer this wave needs: lane l -> hop l/(rpw+1), row l%(rpw+1)
+    int64_t rp = 0;
+    {
+        const int hs = lane / (rpw + 1), r = lane % (rpw + 1);
+        if (hs < n_sel && r <= rows_here) rp = p.hop[hs].rowptr[row0 + r];
+    }
+    const int rp_lo = (int)(rp & 0xffffffff), rp_hi = (int)(rp >> 32);
+    auto seg_bound = [&](int l) -> int64_t {
+        return ((int64_t)__builtin_amdgcn_readlane(rp_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(rp_lo, l);
+    };
+
+    if constexpr (SHORT && EXACT && (kWave / LPR == 2 || kWave / LPR == 4)) {
+        in_tile_short_rows<VEC, LPR, SUM, OFF32, EPI, FB>(p, lane, rpw, row0, rows_here, rp_lo, rp_hi, (int64_t)lane_off0, src_col_begin, lcol, ecol);
+        return;
+    }
     if constexpr (PIPE && EXACT) {
         // ---- software-pipelined walk over the wave's (row, hop) segments: prefetch the next segment's first
         //      index chunk before gathering the current one ----
@@ -808,7 +1089,8 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? (FB == 4 && !SUM ? H2GCN_S
             bool skip_row = false;  // a workgroup of the long path owns rows with any long segment
             for (int s = 0; s < n_sel; ++s) {
                 const int l0 = s * (rpw + 1) + r;
-                if (seg_bound(l0 + 1) - seg_bound(l0) >= p.long_threshold) skip_row = true;
+                const int64_t len = seg_bound(l0 + 1) - seg_bound(l0);
+                if (len >= p.long_threshold) skip_row = true;
             }
             if (skip_row) continue;
         }
@@ -816,6 +1098,10 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? (FB == 4 && !SUM ? H2GCN_S
             const bool lane_active = EXACT || (col0 + li * VEC < p.d);
             float acc[NP][VEC];
             zero_acc<VEC, NP>(acc);
+#ifdef H2GCN_DEFER_HOP_STORES   // A/B builds only: a row's first hop total is held until the second is ready, so that the
+            float held[VEC];            // two pieces of Y[row, :, slice] leave back to back (profiles/r04_ab_output_stores.txt)
+            int held_s = -1;
+#endif
             for (int s = 0; s < n_sel; ++s) {
                 const int l0 = s * (rpw + 1) + r;
                 const int64_t sb = seg_bound(l0), se = seg_bound(l0 + 1);
@@ -827,11 +1113,30 @@ __global__ __launch_bounds__(kBlock, EXACT ? (SHORT ? (FB == 4 && !SUM ? H2GCN_S
                 if constexpr (!SUM) {
                     float tot[VEC];
                     fold_tree<VEC, LPR, NP>(acc, tot);
+#ifdef H2GCN_DEFER_HOP_STORES
+                    if (EXACT && n_sel == 2 && s == 0) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) held[i] = tot[i];
+                        held_s = 0;
+                    } else {
+                        if (held_s >= 0 && g == 0 && lane_active)
+                            store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + p.dst_hop_off[held_s], lcol, ecol, held);
+                        held_s = -1;
+                        if (g == 0 && lane_active)
+                            store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + p.dst_hop_off[s], EXACT ? lcol : col0 + li * VEC, EXACT ? ecol : col0 + li * VEC, tot);
+                    }
+#else
                     if (g == 0 && lane_active)
                         store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + p.dst_hop_off[s], EXACT ? lcol : col0 + li * VEC, EXACT ? ecol : col0 + li * VEC, tot);
+#endif
                     zero_acc<VEC, NP>(acc);
                 }
             }
+#ifdef H2GCN_DEFER_HOP_STORES
+            if constexpr (!SUM)
+                if (held_s >= 0 && g == 0 && lane_active)
+                    store_out<VEC, EPI>(p, p.dst + row * p.ld_dst + p.dst_hop_off[held_s], lcol, ecol, held);
+#endif
             if constexpr (SUM) {
                 float tot[VEC];
                 fold_tree<VEC, LPR, NP>(acc, tot);
@@ -882,16 +1187,6 @@ __global__ void repack_slice_major_kernel(const float* __restrict__ x, int64_t l
             __builtin_nontemporal_store(col < d ? *src : 0.f, w + i);
         }
     }
-}
-
-// one-time operand check of plan_create: any column id outside [0, n_cols) raises the flag
-__global__ void check_colidx_kernel(const int32_t* __restrict__ colidx, int64_t nnz, int64_t n_cols, int* flag) {
-    int bad = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t c = colidx[i];
-        bad |= (c < 0) | ((int64_t)c >= n_cols);
-    }
-    if (bad) atomicOr(flag, 1);
 }
 
 }  // namespace h2gcn

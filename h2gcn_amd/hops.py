@@ -4,8 +4,9 @@ Mirror of what the reference keeps in ``args.objects["tensors"]["adj_hops"]``: a
 ``tf.SparseTensor`` built once before training (reference ``h2gcn/models/H2GCN.py:46-54`` ->
 ``h2gcn/datasets/_dataset.py:559-576``, conversion ``sparse2Tensor`` ``:528-535``).  Here the list is one object:
 CSR arrays on the GPU (int64 row pointers, int32 column ids in ascending order per row -- the canonical order
-``tf.sparse.reorder`` establishes -- fp32 values) plus the opaque plan of ``libh2gcn_hip.so`` (row bins of the
-CSR-adaptive schedule, optional transposed operands for the backward pass).
+``tf.sparse.reorder`` establishes -- fp32 values) plus the opaque plan of ``libh2gcn_hip.so`` (the segment-class bins of the
+CSR-adaptive schedule: lists of the long and of the short (row, hop) segments, see :meth:`HopPlan.segment_classes`;
+optional transposed operands for the backward pass).
 """
 from __future__ import annotations
 
@@ -149,8 +150,28 @@ class HopPlan:
         _capi.check(L.h2gcn_plan_schedule(self._handle, self._mask(hops), 1 if adjoint else 0, ld, int(d),
                                           C.byref(sc), C.byref(ns), C.byref(pf), C.byref(cp)))
         return dict(slice_cols=sc.value, n_slices=ns.value,
-                    segment_walk={0: "wave per segment", 1: "wave per segment + index prefetch", 2: "lane group per segment (short rows)"}[pf.value],
+                    segment_walk={0: "wave per segment", 1: "wave per segment + index prefetch",
+                                  2: "lane group per segment (short rows)",
+                                  3: "lane group per segment (binned short segments) + wave per segment"}[pf.value],
                     scratch_copy=bool(cp.value) and self.use_workspace)
+
+    def segment_classes(self, d: int, ld_src: Optional[int] = None, hops=None, adjoint: bool = False) -> dict:
+        """CSR-adaptive dispatch of a launch at width ``d``: per selected hop the number of short (<= 16 nonzeros) / medium /
+        long (>= long_row_threshold) segments and their nonzeros, which walk serves each class, and how many segments the
+        launch takes from the binned short list (``listed``; 0 = the wave walk serves the short class too, -1 = in-tile
+        short-row mode: rounds of consecutive short rows are grouped on the fly)."""
+        L = _capi.lib()
+        h_sel = self.n_selected(hops)
+        seg, nnz, listed = (C.c_int64 * (3 * h_sel))(), (C.c_int64 * (3 * h_sel))(), C.c_int64()
+        ld = int(ld_src) if ld_src is not None else (h_sel * d if adjoint else d)
+        _capi.check(L.h2gcn_plan_segment_classes(self._handle, self._mask(hops), 1 if adjoint else 0, ld, int(d), seg, nnz, C.byref(listed)))
+        sel = list(range(self.n_hops)) if hops is None else sorted({int(h) for h in hops})
+        short_walk = ("lane group per segment (binned list)" if listed.value > 0 else
+                      "lane group per segment (rounds of consecutive short rows)" if listed.value < 0 else "wave per segment")
+        per_hop = [dict(hop=sel[s], segments=dict(short=seg[3 * s], medium=seg[3 * s + 1], long=seg[3 * s + 2]),
+                        nonzeros=dict(short=nnz[3 * s], medium=nnz[3 * s + 1], long=nnz[3 * s + 2])) for s in range(h_sel)]
+        return dict(per_hop=per_hop, listed=listed.value,
+                    walks=dict(short=short_walk, medium="wave per segment", long="workgroup per segment (4 waves, LDS-staged)"))
 
     def _mask(self, hops) -> int:
         if hops is None:

@@ -92,6 +92,18 @@ def synth_degrees_lognormal(n_rows: int, nnz_target: int, seed: int, n_cols: int
     return np.minimum(deg, n_cols)
 
 
+def synth_degrees_mix(n_rows: int, seed: int, n_cols: int, mix, jitter: int = 2, empty_frac: float = 0.01) -> np.ndarray:
+    """Raw degrees drawn from a discrete mix ``[(fraction, degree), ...]`` (+- ``jitter``), rows in random order: short rows
+    scattered among medium ones at a prescribed share (stress shape for the dispatch by segment class)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    fr = np.array([f for f, _ in mix], dtype=np.float64)
+    which = rng.choice(len(mix), size=n_rows, p=fr / fr.sum())
+    deg = np.array([d for _, d in mix], dtype=np.int64)[which] + rng.integers(-jitter, jitter + 1, n_rows)
+    deg = np.maximum(deg, 1)
+    deg[rng.random(n_rows) < empty_frac] = 0
+    return np.minimum(deg, n_cols)
+
+
 def hop_degrees(cfg: dict, seeds=None) -> list:
     """Raw degree sequences of the hop matrices of one entry of :data:`SHAPES` (identical on every rank)."""
     seeds = seeds or (SEED_A1, SEED_A2)
@@ -104,7 +116,10 @@ def hop_degrees(cfg: dict, seeds=None) -> list:
             out.append(synth_degrees(cfg["n"], nnz[k], s, cfg["n"]))
         else:
             sp = spec[k] if isinstance(spec, (list, tuple)) else spec
-            out.append(synth_degrees_lognormal(cfg["n"], nnz[k], s, cfg["n"], sigma=sp["sigma"]))
+            if "mix" in sp:
+                out.append(synth_degrees_mix(cfg["n"], s, cfg["n"], sp["mix"]))
+            else:
+                out.append(synth_degrees_lognormal(cfg["n"], nnz[k], s, cfg["n"], sigma=sp["sigma"]))
     return out
 
 
@@ -192,5 +207,8 @@ SHAPES = {
                        degrees=[dict(sigma=1.0), dict(sigma=1.0)]),       # A1 mean 8 (median 5), A2 mean 100 (median 60)
     "products_tail": dict(n=2_400_000, nnz_per_hop=120_000_000, d=128,
                           degrees=dict(sigma=1.35)),                      # products' |V|, |E|; degrees from 1, ~43 % of rows < 16
+    # 60 % of the rows with ~10 nonzeros scattered among 40 % with ~30: mean 18 (a "wave per segment" launch by the pooled
+    # mean) although a third of the EDGES sits in short segments; X = 4.1 GB
+    "bimodal": dict(n=8_000_000, nnz_per_hop=142_500_000, d=128, degrees=dict(mix=[(0.6, 10), (0.4, 30)])),
 }
 SEED_A1, SEED_A2, SEED_X = 123, 124, 125

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define H2GCN_ABI_VERSION 3
+#define H2GCN_ABI_VERSION 4
 #define H2GCN_MAX_HOPS 8
 
 typedef enum h2gcn_status {
@@ -68,13 +68,19 @@ typedef struct h2gcn_plan_opts {
     int32_t long_row_threshold;  /* (row,hop) segments with >= this many nonzeros are split across the
                                     waves of one workgroup (LDS-staged partial sums); default 256          */
     int32_t rows_per_wave;       /* consecutive rows a wave walks in the regular path; default 4           */
-    int32_t variant;             /* segment walk of the kernel: 0 = default (segments averaging >= 16 nonzeros:
-                                    one wave per segment; shorter: short-row mode -- one lane group per segment --
-                                    when the slice is 64 or 128 columns, else the wave walk with index prefetch
-                                    across segments); 1 = scalar-addressed float2 gathers at d=128; 2 = always
-                                    prefetch; 3 = plain wave walk; 4 = default, but never use the slice-major
-                                    scratch copy (A/B measurements); 5 = force the short-row mode.  Variants
-                                    0, 2, 3, 4, 5 give identical bits.                                          */
+    int32_t variant;             /* segment walks of the kernel: 0 = default, CSR-adaptive -- long segments
+                                    (>= long_row_threshold): one workgroup each, always; launches whose segments
+                                    average < 16 nonzeros: in-tile short-row mode (G consecutive short rows per
+                                    round, one lane group each) when the slice is 64 or 128 columns, else the wave
+                                    walk with index prefetch across segments; MIXED launches (mean >= 16 but at
+                                    least 5 % of the segments have <= 16 nonzeros, slice 64 / 128): list-driven by
+                                    segment class -- short segments from the plan's binned list, one lane group
+                                    each, medium ones one wave each; otherwise one wave per segment.
+                                    1 = scalar-addressed float2 gathers at d=128; 2 = wave walk, always prefetch;
+                                    3 = plain wave walk; 4 = default, but never use the slice-major scratch copy
+                                    (A/B measurements); 5 = force the in-tile short-row mode; 6 = force the
+                                    list-driven launch (whenever a short segment exists).  Variants 0, 2, 3, 4, 5,
+                                    6 give identical bits.                                                      */
     int32_t slice_cols;          /* feature columns per slice of the slice-major schedule: 64 / 128 / 256,
                                     0 = heuristic (narrower slices when X is far beyond the Infinity Cache).
                                     All three give identical bits (one canonical summation tree); widths
@@ -82,7 +88,7 @@ typedef struct h2gcn_plan_opts {
     int32_t reserved[2];
 } h2gcn_plan_opts;
 
-/* Opaque: row-bin tables (long-segment list), optional transposed CSR, launch geometry. */
+/* Opaque: segment-class bins (long-segment lists, binned short-segment lists), optional transposed CSR, launch geometry. */
 typedef struct h2gcn_plan h2gcn_plan_t;
 
 /* ABI version of the loaded library (== H2GCN_ABI_VERSION it was built with). */
@@ -135,11 +141,24 @@ int h2gcn_plan_info(const h2gcn_plan_t* plan, int hop, int64_t* n_rows, int64_t*
 
 /* The schedule a launch of this plan would use for feature width d and source row stride ld_src (reports, tests):
  * columns per slice of the slice-major schedule, number of slices, segment walk (0 = wave per segment, 1 = the same
- * with index prefetch across segments, 2 = short-row mode: one lane group per segment), whether a launch that is given
+ * with index prefetch across segments, 2 = in-tile short-row mode: rounds of consecutive short rows one lane group per
+ * segment, 3 = list-driven by segment class: short segments from the binned list, one lane group each, medium ones one wave
+ * each -- see h2gcn_plan_segment_classes), whether a launch that is given
  * scratch would gather from a slice-major copy.  adjoint != 0 asks about h2gcn_spmm_hops_T_f32 (ld_src = ldg_row,
  * hop stride d).  Any out pointer may be NULL. */
 int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, int64_t ld_src, int32_t d,
                         int32_t* slice_cols, int32_t* n_slices, int32_t* segment_walk, int32_t* scratch_copy);
+
+/* CSR-adaptive dispatch, introspection: the plan bins every (row, hop) segment by length -- short (<= 16 nonzeros, empty
+ * ones included), medium, long (>= long_row_threshold) -- and a launch serves each class with its own walk (see
+ * h2gcn_plan_opts.variant).  For the s-th selected hop, segments[3 s + {0, 1, 2}] / nonzeros[3 s + {0, 1, 2}] receive the
+ * number of short / medium / long segments and the nonzeros they hold (adjoint != 0: of A_k^T); *listed receives how many
+ * segments (adjoint: output rows, i.e. rows whose segments of ALL selected hops are short) a launch at width d / source
+ * stride ld_src serves from the binned short list -- 0 when that launch leaves the short class to the wave walk, -1 when it
+ * runs in the in-tile short-row mode (rounds of consecutive short rows are grouped on the fly, no list).  Any out
+ * pointer may be NULL; segments / nonzeros need 3 * (number of selected hops) entries. */
+int h2gcn_plan_segment_classes(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint, int64_t ld_src, int32_t d,
+                               int64_t* segments, int64_t* nonzeros, int64_t* listed);
 
 /*
  * Fused multi-hop aggregation, forward:

@@ -33,7 +33,7 @@ def _csr(rng, n_rows, n_cols, mean_deg, heavy, empty_frac):
        d=st.sampled_from([1, 2, 5, 8, 16, 32, 48, 64, 67, 96, 128, 130, 160, 256, 320]), n_hops=st.integers(1, 3),
        mean_deg=st.sampled_from([0.3, 3.0, 20.0, 70.0]), heavy=st.booleans(),
        threshold=st.sampled_from([0, 4, 64, 300]), rpw=st.sampled_from([0, 1, 3, 7]),
-       variant=st.sampled_from([0, 1, 2, 3, 5]), slice_cols=st.sampled_from([0, 64, 128, 256]),
+       variant=st.sampled_from([0, 1, 2, 3, 5, 6]), slice_cols=st.sampled_from([0, 64, 128, 256]),
        mask_bits=st.integers(0, 7))
 def test_random_operands_and_schedules(seed, n_rows, n_cols, d, n_hops, mean_deg, heavy, threshold, rpw, variant,
                                        slice_cols, mask_bits):

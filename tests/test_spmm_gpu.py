@@ -270,8 +270,7 @@ def test_schedule_heuristics_are_what_the_documentation_says():
     lowdeg_like = plan(4000, 8_000_000, 4, 3)              # mean degree 4
     s = lowdeg_like.schedule(128)
     assert s["segment_walk"].startswith("lane group per segment") and s["slice_cols"] == 128
-    assert lowdeg_like.schedule(128, adjoint=True)["segment_walk"] in ("wave per segment", "lane group per segment (short rows)",
-                                                                       "wave per segment + index prefetch")
+    assert lowdeg_like.schedule(128, adjoint=True)["segment_walk"].startswith(("wave per segment", "lane group per segment"))
     s32 = lowdeg_like.schedule(32)                                                      # d < 64: one masked 64-column slice
     assert s32["slice_cols"] == 64 and s32["n_slices"] == 1 and s32["segment_walk"].startswith("lane group per segment")
     small = plan(3000, 3000, 20, 4)
@@ -455,7 +454,7 @@ def test_column_slices_do_not_change_results(d):
 @pytest.mark.parametrize("thr", [0, 20, 100])
 def test_bits_are_the_canonical_tree_for_every_schedule(d, thr):
     """SURVEY.md 8(e) "Determinism": the bits of Y must not depend on how the work was scheduled.  Every segment walk
-    (variants 0 / 2 / 3 / 5), every slice width >= 64, launches with and without scratch (incl. the zero-padded copy of
+    (variants 0 / 2 / 3 / 5 / 6), every slice width >= 64, launches with and without scratch (incl. the zero-padded copy of
     odd widths and the generic column-tiled kernel), FEATURE CHUNKS of different widths, row blocks, hop selections and
     the adjoint all reproduce ONE function of the inputs: the canonical tree restated in oracle/spmm_oracle.c."""
     from h2gcn_amd import HopPlan
@@ -479,7 +478,7 @@ def test_bits_are_the_canonical_tree_for_every_schedule(d, thr):
     tree_t = og.gcn_layer_grad_tree(hops, w, n, long_threshold=thr_eff)
     assert_close(tree, hops, x)
     xt, wt = torch.from_numpy(x).to(dev()), torch.from_numpy(w).to(dev())
-    for variant in (0, 2, 3, 5):
+    for variant in (0, 2, 3, 5, 6):
         for sc in (0, 64, 128, 256):
             plan = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr, variant=variant, slice_cols=sc)
             for use_ws in (True, False):
@@ -548,14 +547,116 @@ def test_short_row_mode_is_bitwise_identical(d, mean_deg):
         ref = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr, variant=3)
         for rpw in (0, 1, 3, 7):
             for sc in (0, 64, 128):
-                alt = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr, variant=5, rows_per_wave=rpw, slice_cols=sc)
-                base = ref   # one canonical tree: the plain walk at the default slice width is the target for every slice width
-                assert torch.equal(base.spmm(x), alt.spmm(x)), (thr, rpw, sc)
-                assert torch.equal(base.spmm_t(w), alt.spmm_t(w)), (thr, rpw, sc)
-                assert torch.equal(base.spmm(x, hops=[1]), alt.spmm(x, hops=[1]))
-                assert torch.equal(base.spmm_t(w[:, :1].contiguous(), hops=[0]), alt.spmm_t(w[:, :1].contiguous(), hops=[0]))
+                for variant in (5, 6):   # in-tile short-row mode / list-driven by segment class
+                    alt = HopPlan.from_scipy(hops, dev(), build_transpose=True, long_row_threshold=thr, variant=variant, rows_per_wave=rpw, slice_cols=sc)
+                    base = ref   # one canonical tree: the plain walk at the default slice width is the target for every slice width
+                    assert torch.equal(base.spmm(x), alt.spmm(x)), (thr, rpw, sc, variant)
+                    assert torch.equal(base.spmm_t(w), alt.spmm_t(w)), (thr, rpw, sc, variant)
+                    assert torch.equal(base.spmm(x, hops=[1]), alt.spmm(x, hops=[1]))
+                    assert torch.equal(base.spmm_t(w[:, :1].contiguous(), hops=[0]), alt.spmm_t(w[:, :1].contiguous(), hops=[0]))
     assert_close(ref.spmm(x).cpu().numpy(), hops, x.cpu().numpy())
     assert alt.schedule(d)["segment_walk"].startswith(("lane group", "wave per segment"))
+
+
+def _mixed_hops(rng, n, kinds):
+    """Hop matrices with prescribed degree mixes: "sparse" (mean 3, all short), "dense" (mean 60), "mixed" (short rows
+    scattered among medium and long ones -- a degree sequence that starts at 1), empty rows everywhere."""
+    hops = []
+    for kind in kinds:
+        if kind == "sparse":
+            deg = rng.poisson(3, n)
+        elif kind == "dense":
+            deg = rng.poisson(60, n)
+        else:
+            deg = np.floor(np.exp(1.3 * rng.standard_normal(n)) * 12 + 0.5).astype(np.int64)
+            deg[rng.integers(0, n, 5)] = [16, 17, 255, 256, 700]
+        deg = np.minimum(deg, n)
+        deg[rng.random(n) < 0.05] = 0
+        rows = np.repeat(np.arange(n), deg)
+        cols = np.concatenate([rng.choice(n, kk, replace=False) for kk in deg])
+        m = sp.csr_matrix((rng.uniform(-1, 1, len(rows)).astype(np.float32), (rows, cols)), shape=(n, n))
+        m.sort_indices()
+        hops.append(m)
+    return hops
+
+
+@pytest.mark.parametrize("kinds", [("sparse", "dense"), ("mixed", "mixed"), ("sparse", "mixed", "dense"),
+                                   ("sparse", "sparse", "mixed", "sparse", "dense")])
+@pytest.mark.parametrize("d", [64, 128])
+def test_csr_adaptive_segment_classes_in_one_launch(kinds, d):
+    """CSR-adaptive dispatch by segment class (round 4): a launch whose selected hops hold short, medium and long
+    segments side by side -- a sparse 1-hop matrix next to a dense 2-hop one (the reference's rings,
+    h2gcn/datasets/_dataset.py:138-158), short rows scattered among long ones -- serves the short class from the plan's
+    binned list (one lane group per segment), the long class by workgroups and the rest by the wave walk, all in ONE
+    launch, and the bits are still the canonical tree's: equal to the plain wave walk (variant 3) and to the oracle's
+    restatement, forward / hop subsets / adjoint (the SUM-mode list serves selections of up to 4 hops; 5 fall back)."""
+    from h2gcn_amd import HopPlan
+
+    rng = np.random.default_rng(len(kinds) * 100 + d)
+    n = 2600   # > 256 listed entries per hop: several list workgroups and a partial last wave
+    hops = _mixed_hops(rng, n, kinds)
+    H = len(hops)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    w = rng.uniform(-1, 1, (n, H, d)).astype(np.float32)
+    xt, wt = torch.from_numpy(x).to(dev()), torch.from_numpy(w).to(dev())
+    tree = og.gcn_layer_tree(hops, x)
+    tree_t = og.gcn_layer_grad_tree(hops, w, n)
+    assert_close(tree, hops, x)
+    ref = HopPlan.from_scipy(hops, dev(), build_transpose=True, variant=3)
+    for variant in (0, 6, 5):      # default (mean >= 16, many short segments: list-driven), forced lists, forced in-tile mode
+        for sc in (0, 64, 128):
+            for rpw in (0, 1, 7):
+                plan = HopPlan.from_scipy(hops, dev(), build_transpose=True, variant=variant, slice_cols=sc, rows_per_wave=rpw)
+                cls = plan.segment_classes(d)
+                if variant == 5:
+                    assert cls["listed"] == -1 and plan.schedule(d)["segment_walk"] == "lane group per segment (short rows)"
+                else:
+                    assert cls["listed"] > 0 and cls["walks"]["short"] == "lane group per segment (binned list)", (variant, sc, cls)
+                    assert plan.schedule(d)["segment_walk"].startswith("lane group per segment (binned")
+                y = plan.spmm(xt)
+                assert np.array_equal(y.cpu().numpy(), tree), (variant, sc, rpw)
+                assert torch.equal(y, ref.spmm(xt))
+                dx = plan.spmm_t(wt)
+                assert np.array_equal(dx.cpu().numpy(), tree_t), (variant, sc, rpw, "adjoint")
+                sel = [0, H - 1]
+                assert torch.equal(plan.spmm(xt, hops=sel), ref.spmm(xt, hops=sel))
+                assert torch.equal(plan.spmm_t(wt[:, sel].contiguous(), hops=sel), ref.spmm_t(wt[:, sel].contiguous(), hops=sel))
+                assert torch.equal(plan.spmm(xt, hops=[H - 1]), ref.spmm(xt, hops=[H - 1]))
+    # the per-hop classes add up, and name the sparse hop as (almost) entirely short
+    cls = HopPlan.from_scipy(hops, dev(), build_transpose=True).segment_classes(d)
+    for k, (hop, m) in enumerate(zip(cls["per_hop"], hops)):
+        lens = np.diff(m.indptr)
+        assert hop["segments"] == dict(short=int((lens <= 16).sum()), medium=int(((lens > 16) & (lens < 256)).sum()), long=int((lens >= 256).sum()))
+        assert hop["nonzeros"] == dict(short=int(lens[lens <= 16].sum()), medium=int(lens[(lens > 16) & (lens < 256)].sum()),
+                                       long=int(lens[lens >= 256].sum()))
+    assert cls["listed"] == sum(h["segments"]["short"] for h in cls["per_hop"])
+    # odd widths / fused epilogues run on the general-store kernels: no list there, same bits
+    xo = xt[:, : d - 3].contiguous()
+    plan = HopPlan.from_scipy(hops, dev(), variant=6)
+    assert plan.segment_classes(d - 3)["listed"] == 0
+    assert np.array_equal(plan.spmm(xo).cpu().numpy(), og.gcn_layer_tree(hops, x[:, : d - 3]))
+
+
+def test_cora_one_hop_ring_is_served_by_the_binned_list():
+    """The reference's own operands are bimodal (exact-1-hop ring: mean 3.9 nonzeros per row, exact-2-hop ring: 31.9): the
+    pooled mean (17.9) used to put the WHOLE launch on the wave walk; now A1's segments are listed and served one lane
+    group each while A2's longer ones keep the wave walk -- and the result is the stored golden one."""
+    from h2gcn_amd import HopPlan
+
+    g = load_planetoid_golden("cora")
+    hops = [g["hop1_sym"], g["hop2_sym"]]
+    plan = HopPlan.from_scipy(hops, dev(), build_transpose=True)
+    for d in (64, 128):
+        cls = plan.segment_classes(d)
+        a1, a2 = cls["per_hop"]
+        assert a1["segments"]["short"] >= 0.97 * g["n"] and a2["segments"]["medium"] > 0.4 * g["n"]
+        assert cls["listed"] == a1["segments"]["short"] + a2["segments"]["short"]
+        assert cls["walks"] == dict(short="lane group per segment (binned list)", medium="wave per segment",
+                                    long="workgroup per segment (4 waves, LDS-staged)")
+        x = np.random.default_rng(d).uniform(-1, 1, (g["n"], d)).astype(np.float32)
+        y = plan.spmm(torch.from_numpy(x).to(dev())).cpu().numpy()
+        assert np.array_equal(y, og.gcn_layer_tree(hops, x))
+        assert_close(y, hops, x)
 
 
 def test_variant_scalar_addressing_matches():
