@@ -29,8 +29,10 @@ sys.path.insert(0, str(ROOT))
 #: order-independent fingerprint of Y (sum of the fp32 bit patterns as int64) of the default single-GPU line per (shape, d):
 #: the per-row summation tree is canonical, so EVERY schedule -- any rank count, exchange, chunking, slice width -- must
 #: reproduce it bit for bit (SURVEY.md 8(e) "Determinism"); N > 1 lines report `checksum_matches_n1` against this table
-#: (measured: BENCH_r03.json / profiles/r04_checksums.json)
-N1_CHECKSUMS = {("products", 128): -26948829970322352}
+#: (measured: BENCH_r03.json for products; the bench lines behind profiles/r04_*_summary.json for the rest)
+N1_CHECKSUMS = {("products", 128): -26948829970322352, ("products", 64): -13319257904282617, ("arxiv", 128): -1390319019045034,
+                ("h2gcn_like", 128): -20343064339982979, ("products_tail", 128): -25034865256373447,
+                ("lowdeg", 128): -57806506298044835, ("hbm16m", 128): -132311004237956237, ("products_x6", 128): -179026745709730822}
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
 

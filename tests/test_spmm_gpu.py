@@ -963,9 +963,10 @@ def test_errors_are_python_exceptions_before_or_at_the_c_call():
 
 
 # ----------------------------------------------------------------------------- BASELINE shapes, size-independent properties
-@pytest.mark.parametrize("shape", ["arxiv", "products", "lowdeg"])
+@pytest.mark.parametrize("shape", ["arxiv", "products", "lowdeg", "h2gcn_like", "products_tail"])
 def test_baseline_shapes_properties(shape):
-    """configs[2] / configs[3] at FULL size (+ the mean-degree-4 stress shape, which runs the short-row kernels): (1) row-stochastic hops map the all-ones features to ones on every
+    """configs[2] / configs[3] at FULL size (+ the mean-degree-4 stress shape, which runs the in-tile short-row kernels, and the two
+    mixed-class shapes, which run list-driven): (1) row-stochastic hops map the all-ones features to ones on every
     non-empty row and zeros on empty rows; (2) linearity; (3) sampled rows against the fp64 oracle, the CPU
     regenerating those rows of the operands independently (counter-based generator)."""
     from h2gcn_amd import HopPlan, synth
@@ -973,11 +974,15 @@ def test_baseline_shapes_properties(shape):
     cfg = synth.SHAPES[shape]
     n, d = cfg["n"], cfg["d"]
     device = dev()
-    degs = [synth.synth_degrees(n, cfg["nnz_per_hop"], s, n) for s in (synth.SEED_A1, synth.SEED_A2)]
+    degs = synth.hop_degrees(cfg)
     csr = [synth.synth_hop_rows(degs[k], n, (synth.SEED_A1, synth.SEED_A2)[k], 0, n, device) for k in range(2)]
     plan = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n)
     nnz = plan.nnz
-    assert all(abs(z - cfg["nnz_per_hop"]) < 0.01 * cfg["nnz_per_hop"] for z in nnz)
+    want_nnz = cfg["nnz_per_hop"] if isinstance(cfg["nnz_per_hop"], (list, tuple)) else [cfg["nnz_per_hop"]] * 2
+    assert all(abs(z - t) < 0.01 * t for z, t in zip(nnz, want_nnz))
+    walk = plan.schedule(d)["segment_walk"]
+    assert walk.startswith({"lowdeg": "lane group per segment (short rows)", "arxiv": "lane group per segment (short rows)",
+                            "h2gcn_like": "lane group per segment (binned", "products_tail": "lane group per segment (binned"}.get(shape, "wave per segment")), walk
     x = synth.synth_features(d, synth.SEED_X, 0, n, device)
     y = plan.spmm(x)
     # (1) row-stochastic
