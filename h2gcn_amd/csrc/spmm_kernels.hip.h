@@ -391,7 +391,7 @@ __device__ __forceinline__ void accumulate_segment(const int32_t* __restrict__ c
 // still gathering, and every further chunk is fetched before the current one is processed -- the index fetch
 // latency leaves the per-segment dependency chain (index -> gather -> fold -> store), which is what bounds
 // short rows.  Loads retire in order, so waiting for the gathers implies the prefetch has landed.
-template <int VEC, int LPR, bool OFF32, int NP>
+template <int VEC, int LPR, bool OFF32, int MAXB = H2GCN_MAIN_MAXB, int NP>
 __device__ __forceinline__ void accumulate_segment_prefetched(const int32_t* __restrict__ colidx,
                                                               const float* __restrict__ vals, int64_t seg_begin,
                                                               int64_t seg_end, int c, float v,
@@ -404,7 +404,7 @@ __device__ __forceinline__ void accumulate_segment_prefetched(const int32_t* __r
         int c_next = 0;
         float v_next = 0.f;
         if (left > kWave) load_chunk(colidx, vals, base + kWave, seg_end, lane, c_next, v_next);
-        process_chunk<VEC, LPR, false, OFF32>(c, v, n, g, addr, true, acc);
+        process_chunk<VEC, LPR, false, OFF32, MAXB>(c, v, n, g, addr, true, acc);
         c = c_next;
         v = v_next;
     }
@@ -681,14 +681,19 @@ __device__ __forceinline__ void medium_list_blocks(const LaunchParams& p, int64_
         }
     }
     const int b0_lo = (int)(b0 & 0xffffffff), b0_hi = (int)(b0 >> 32), b1_lo = (int)(b1 & 0xffffffff), b1_hi = (int)(b1 >> 32);
+    auto bounds = [&](int l, int64_t& sb, int64_t& se) {
+        sb = ((int64_t)__builtin_amdgcn_readlane(b0_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(b0_lo, l);
+        se = ((int64_t)__builtin_amdgcn_readlane(b1_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(b1_lo, l);
+    };
+    // (Fetching the first index chunk of segment i+1 before segment i gathers -- the tile walk's PIPE trick -- was tried here:
+    // products_tail +1.5-2 %, h2gcn_like +0.5 %, but bimodal -4 to -10 %; not kept, profiles/r04_ab_short_walks.txt.)
     for (int j = 0; j < n_here; ++j) {
         const int64_t orow = __builtin_amdgcn_readlane(row, j * NS);
         float acc[NP][VEC];
         zero_acc<VEC, NP>(acc);
         for (int s = 0; s < NS; ++s) {
-            const int l = j * NS + s;
-            const int64_t sb = ((int64_t)__builtin_amdgcn_readlane(b0_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(b0_lo, l);
-            const int64_t se = ((int64_t)__builtin_amdgcn_readlane(b1_hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(b1_lo, l);
+            int64_t sb, se;
+            bounds(j * NS + s, sb, se);
             const int hs = SUM ? s : hop;
             const HopCsr& h = p.hop[hs];
             const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[hs] + src_col_begin - VEC), (off_t)lane_off0,
