@@ -281,6 +281,10 @@ int get_long_list(const h2gcn_plan* plan, bool adjoint, uint32_t mask, const int
     return H2GCN_OK;
 }
 
+// wave-sized work items a launch should have before a wave is given more than the minimum work: ~2 per wave slot of the
+// chip (256 CUs x 4 SIMDs x 6 waves)
+constexpr int64_t kWavesToFill = 12288;
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Column-slice width of the EXACT kernels (float4 lanes; any d >= 4, any 4-byte aligned operands: 16-byte global loads
@@ -453,21 +457,26 @@ int launch(LaunchParams& p, const h2gcn_plan* plan, const LaunchShape& sh, bool 
     if (lists) {
         // list-driven launch: short-list workgroups serve 4 waves x 64 entries, medium-list workgroups 4 waves x
         // med_per_wave entries; forward -- one run of workgroups per selected hop and class
-        p.med_per_wave = SUM ? std::max(1, std::min(p.rows_per_wave, kWave / p.n_sel)) : std::min(2 * p.rows_per_wave, 16);
-        static const int env_mpw = getenv("H2GCN_MED_PER_WAVE") ? atoi(getenv("H2GCN_MED_PER_WAVE")) : 0;
-        if (env_mpw >= 1 && env_mpw * p.n_sel <= kWave) p.med_per_wave = env_mpw;
-        int64_t sblocks = 0, mblocks = 0, n_listed = 0, longest = 0;
+        int64_t n_listed = 0, n_med = 0, longest = 0;
         for (int s = 0; s < sh.n_short_lists; ++s) {
             n_listed += sh.short_count[s];
+            n_med += sh.med_count[s];
             longest = std::max(longest, sh.short_count[s]);
         }
-        // entries per lane-group wave: 64 (one coalesced list read, 16-32 rounds per wave) on big operands; fewer on
-        // small ones, so that the launch still has several waves per SIMD slot of the chip (arxiv shape: 0.3M entries)
+        // entries per wave follow the size of the launch (see kWavesToFill): a medium-list wave walks up to 8 segments
+        // (SUM: 4 rows), a lane-group wave serves up to 64 entries (one coalesced list read, 16-32 rounds) -- fewer on small
+        // operands, so that the launch still has a couple of waves per wave slot of the chip
+        static const int env_mpw = getenv("H2GCN_MED_PER_WAVE") ? atoi(getenv("H2GCN_MED_PER_WAVE")) : 0;
         static const int env_spw = getenv("H2GCN_SHORT_PER_WAVE") ? atoi(getenv("H2GCN_SHORT_PER_WAVE")) : 0;
         static const int env_major = getenv("H2GCN_SHORT_HOP_MAJOR") ? atoi(getenv("H2GCN_SHORT_HOP_MAJOR")) : -1;
-        p.short_per_wave = n_listed >= (int64_t)64 * 8 * 256 * 28 ? 64 : (n_listed >= (int64_t)32 * 8 * 256 * 28 ? 32 : 16);
+        const int mpw_max = SUM ? std::max(1, std::min(4, kWave / p.n_sel)) : 8;
+        p.med_per_wave = (int)std::max<int64_t>(1, std::min<int64_t>(n_med / kWavesToFill, mpw_max));
+        if (env_mpw >= 1 && env_mpw * p.n_sel <= kWave) p.med_per_wave = env_mpw;
+        p.short_per_wave = 4;
+        while (p.short_per_wave < 64 && n_listed / (2 * p.short_per_wave) >= kWavesToFill) p.short_per_wave *= 2;
         if (env_spw >= 4 && env_spw <= 64 && env_spw % 4 == 0) p.short_per_wave = env_spw;
         p.short_hop_major = env_major >= 0 ? env_major : 0;
+        int64_t sblocks = 0, mblocks = 0;
         const int64_t s_per_block = (int64_t)kWavesPerBlock * p.short_per_wave;
         for (int s = 0; s < sh.n_short_lists; ++s) {
             p.short_list[s] = sh.short_list[s];
@@ -628,9 +637,19 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
         plan->n_cols = n_cols;
         if (o.long_row_threshold > 0) plan->long_threshold = o.long_row_threshold;
         if (o.rows_per_wave > 0) plan->rows_per_wave = o.rows_per_wave;
+        else if (const char* e = getenv("H2GCN_ROWS_PER_WAVE")) plan->rows_per_wave = std::max(1, std::min(atoi(e), h2gcn::kMaxRowsPerWave));   // experiments
+        else {
+            // work per wave follows the size of the launch: on a graph of a few thousand rows (the reference's own datasets:
+            // Cora 2 708, citeseer 3 327) a launch is a handful of workgroups and its duration is the dependent chain of ONE
+            // wave, so a wave takes one row; from ~50 k rows on the chip is full either way and 4 rows per wave amortise
+            // the prologue (Cora epoch 0.46 -> 0.37 ms with 1 row per wave; arxiv shape 0.193 ms with 4 vs 0.241 with 1:
+            // profiles/r04_ab_work_per_wave.txt).  The row-to-wave assignment is invisible in the bits.
+            plan->rows_per_wave = (int)std::max<int64_t>(1, std::min<int64_t>(n_rows / kWavesToFill, 4));
+        }
         // (rows_per_wave + 1) * n_hops row pointers must fit one 64-lane load
         while ((plan->rows_per_wave + 1) * n_hops > h2gcn::kWave && plan->rows_per_wave > 1) plan->rows_per_wave--;
         plan->variant = o.variant;
+        if (o.variant == 0) if (const char* e = getenv("H2GCN_VARIANT")) plan->variant = atoi(e);   // experiments through the entry points
         plan->slice_cols = o.slice_cols;
         // segment classes: short <= short_max < medium < long_threshold <= long
         plan->short_max = std::min(h2gcn::kShortMax, plan->long_threshold - 1);
