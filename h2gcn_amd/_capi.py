@@ -63,6 +63,9 @@ EXPORTED_SYMBOLS = (
     "h2gcn_masked_metrics_f32",
     "h2gcn_masked_ce_backward_f32",
     "h2gcn_adam_keras_f32",
+    "h2gcn_adam_keras_l2_f32",
+    "h2gcn_l2_penalty_workspace_bytes",
+    "h2gcn_l2_penalty_f32",
     "h2gcn_xchg_create",
     "h2gcn_xchg_export",
     "h2gcn_xchg_connect",
@@ -218,6 +221,16 @@ def lib() -> C.CDLL:
     L.h2gcn_adam_keras_f32.restype = C.c_int
     L.h2gcn_adam_keras_f32.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_int64), C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
+    if hasattr(L, "h2gcn_adam_keras_l2_f32"):   # (absent from pre-ABI-4 builds loaded for A/B runs)
+        L.h2gcn_adam_keras_l2_f32.restype = C.c_int
+        L.h2gcn_adam_keras_l2_f32.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                              C.c_int64, C.c_void_p]
+        L.h2gcn_l2_penalty_workspace_bytes.restype = C.c_size_t
+        L.h2gcn_l2_penalty_workspace_bytes.argtypes = []
+        L.h2gcn_l2_penalty_f32.restype = C.c_int
+        L.h2gcn_l2_penalty_f32.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_void_p, C.c_void_p,
+                                           C.c_size_t, C.c_void_p]
     L.h2gcn_xchg_create.restype = C.c_int
     L.h2gcn_xchg_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.h2gcn_xchg_export.restype = C.c_int

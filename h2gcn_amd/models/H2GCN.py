@@ -127,13 +127,29 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
         use_graphs = False
     optimizer = make_optimizer(optimizer, model.parameters(), lr, capturable=use_graphs)
     snapshot = logger.BestSnapshot()
+    # The keras l2 penalty of the dense kernels (`:239-240, 247-248`): with KerasAdam on the GPU its GRADIENT is folded into the
+    # optimizer's one launch (same roundings as autograd's accumulate) and its VALUE is one more launch -- instead of a pow, a
+    # reduction, a multiply and an add per kernel per loss plus the backward of all that (on Cora ~25 of an epoch's 65 launches,
+    # profiles/r04_cora_epoch_kernels.txt).  Other optimizers / CPU runs keep the penalty inside the autograd graph.
+    from ..optim import KerasAdam
+    fused_l2 = (isinstance(optimizer, KerasAdam) and model.l2 > 0 and bool(model.regularized) and device.type == "cuda"
+                and os.environ.get("H2GCN_FUSED_L2", "1") != "0")
+    if fused_l2:
+        optimizer.set_l2([layer.kernel for layer in model.regularized], model.l2)
+    model.fused_l2 = fused_l2
+    penalty = model.regularization_value if fused_l2 else model.regularization_loss
 
     def train_step(adj, adj_hops, features, y_train, train_mask, **kwargs):
         model.train()
         optimizer.zero_grad(set_to_none=True)
         predictions = model(adj, features, adj_hops)
-        train_loss = model.loss(predictions, y_train, train_mask)
-        train_loss.backward()
+        if fused_l2:
+            data_loss = model.data_loss(predictions, y_train, train_mask)
+            data_loss.backward()
+            train_loss = data_loss.detach() + penalty()    # the penalty of the weights this step STARTED from, as in the reference
+        else:
+            train_loss = model.loss(predictions, y_train, train_mask)
+            train_loss.backward()
         model.restore_sparse_inputs()   # SparseDropout pointed the shared feature operand at dropped values
         optimizer.step()
         model.note_update()
@@ -169,7 +185,7 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
             loss = (nll * c["w_loss"]).sum(dim=1)                                                         # val / test
         return dict(
             train_acc=acc[0], val_acc=acc[1], test_accuracy=acc[2],
-            val_loss=loss[0] + model.regularization_loss(),                          # includes the L2 term (:100)
+            val_loss=loss[0] + penalty(),                                            # includes the L2 term (:100)
             test_loss=loss[1],                                                       # does not (:101-102)
             monitor=dict(),
         )
@@ -324,8 +340,12 @@ def _sharded_steps(model, optimizer):
         optimizer.zero_grad(set_to_none=True)
         predictions = model(adj, features, adj_hops)
         ce = partial_ce(predictions, y_train, train_mask)
-        reg = model.regularization_loss()
-        (ce + reg / world).backward()
+        if getattr(model, "fused_l2", False):     # the penalty's gradient rides in the optimizer step (KerasAdam.set_l2), after the
+            reg = model.regularization_value()    # all-reduce of the data gradients: every replica adds the same 2 * l2 * w
+            ce.backward()
+        else:
+            reg = model.regularization_loss()
+            (ce + reg / world).backward()
         model.restore_sparse_inputs()
         # ONE exchange for every dense-kernel gradient and the loss scalar: flatten, sum over ranks (identical order on
         # every rank: the replicas stay bit-identical), scatter back
@@ -345,7 +365,7 @@ def _sharded_steps(model, optimizer):
         exchange_ok(adj_hops)
         model.eval()
         predictions = model(adj, features, adj_hops)
-        reg = model.regularization_loss()
+        reg = model.regularization_value() if getattr(model, "fused_l2", False) else model.regularization_loss()
         if fused_metrics.supported(predictions):   # one pass over the local logits for all five quantities
             loss3, acc3 = fused_metrics.masked_metrics(predictions, [y_train, y_val, y_test],
                                                        [global_weights(m) for m in (train_mask, val_mask, test_mask)])
@@ -724,6 +744,18 @@ class H2GCN(torch.nn.Module):
         for layer in self.regularized:
             total = total + self.l2 * (layer.kernel ** 2).sum()
         return total
+
+    def regularization_value(self) -> torch.Tensor:
+        """The same quantity WITHOUT a gradient, in one kernel launch when the kernels live on a GPU (``optim.l2_penalty``) -- for
+        step closures that fold the penalty's gradient into the optimizer step (``KerasAdam.set_l2``) and only report its value."""
+        ks = [layer.kernel for layer in self.regularized]
+        if ks and self.l2 > 0 and all(k.is_cuda and k.dtype == torch.float32 and k.is_contiguous() for k in ks) and len(ks) <= 16:
+            from ..optim import l2_penalty
+            return l2_penalty([k.detach() for k in ks], [self.l2] * len(ks))
+        return self.regularization_loss().detach()
+
+    def data_loss(self, predictions, labels, mask) -> torch.Tensor:
+        return masked_softmax_cross_entropy(predictions, labels, mask)
 
     def loss(self, predictions, labels, mask) -> torch.Tensor:
         return masked_softmax_cross_entropy(predictions, labels, mask) + self.regularization_loss()

@@ -24,6 +24,17 @@ class KerasAdam(torch.optim.Optimizer):
         if lr < 0 or not 0 <= beta_1 < 1 or not 0 <= beta_2 < 1 or epsilon < 0:
             raise ValueError(f"KerasAdam: lr {lr}, beta_1 {beta_1}, beta_2 {beta_2}, epsilon {epsilon}")
         super().__init__(params, dict(lr=lr, beta_1=beta_1, beta_2=beta_2, epsilon=epsilon))
+        self._l2 = {}   # id(param) -> coefficient of a keras-style l2 regulariser folded into the step (see set_l2)
+
+    def set_l2(self, params, coefficient: float) -> None:
+        """Fold the gradient of ``coefficient * sum(p ** 2)`` (keras ``regularizers.l2``, reference ``H2GCN.py:239-240,247-248``)
+        of every parameter in ``params`` into the step: the update uses ``p.grad + 2 * coefficient * p`` -- the very value
+        autograd would have accumulated had the penalty been part of the loss (same roundings), without the pow / sum / mul /
+        add launches per kernel.  The caller then keeps the penalty OUT of the autograd graph (``l2_penalty`` gives its value)."""
+        if coefficient < 0:
+            raise ValueError(f"KerasAdam.set_l2: coefficient {coefficient}")
+        for p in params:
+            self._l2[id(p)] = float(coefficient)
 
     def _state(self, p):
         st = self.state[p]
@@ -54,13 +65,17 @@ class KerasAdam(torch.optim.Optimizer):
                 states = [self._state(p) for p in fast]
                 n = len(fast)
                 arr = C.c_void_p * n
+                l2s = [self._l2.get(id(p), 0.0) for p in fast]
                 with torch.cuda.device(fast[0].device):
                     stream = torch.cuda.current_stream(fast[0].device).cuda_stream
-                    _capi.check(_capi.lib().h2gcn_adam_keras_f32(
-                        n, arr(*[p.data_ptr() for p in fast]), arr(*[g.data_ptr() for g in grads]),
-                        arr(*[s["m"].data_ptr() for s in states]), arr(*[s["v"].data_ptr() for s in states]),
-                        (C.c_int64 * n)(*[p.numel() for p in fast]), lr, b1, b2, eps,
-                        C.c_void_p(group["step_dev"].data_ptr()), 0, C.c_void_p(stream)))
+                    common = (n, arr(*[p.data_ptr() for p in fast]), arr(*[g.data_ptr() for g in grads]),
+                              arr(*[s["m"].data_ptr() for s in states]), arr(*[s["v"].data_ptr() for s in states]),
+                              (C.c_int64 * n)(*[p.numel() for p in fast]))
+                    tail = (lr, b1, b2, eps, C.c_void_p(group["step_dev"].data_ptr()), 0, C.c_void_p(stream))
+                    if any(l2s):
+                        _capi.check(_capi.lib().h2gcn_adam_keras_l2_f32(*common, (C.c_float * n)(*l2s), *tail))
+                    else:
+                        _capi.check(_capi.lib().h2gcn_adam_keras_f32(*common, *tail))
                 # the kernel wrote the parameters through raw pointers: tell autograd's version counters, so that anything
                 # keyed by `p._version` (models.H2GCN's propagation reuse) sees the update like after any in-place torch op
                 torch._C._increment_version(fast)
@@ -73,6 +88,8 @@ class KerasAdam(torch.optim.Optimizer):
                 one, tb1, tb2 = (torch.tensor(x, dtype=torch.float32) for x in (1.0, b1, b2))   # fp32 like the kernel
                 alpha = (torch.tensor(lr, dtype=torch.float32) * torch.sqrt(one - tb2 ** t) / (one - tb1 ** t)).item()
                 g = p.grad
+                if self._l2.get(id(p), 0.0):
+                    g = g + p * (2.0 * self._l2[id(p)])
                 st["m"].add_((g - st["m"]) * (one - tb1).item())
                 st["v"].add_((g * g - st["v"]) * (one - tb2).item())
                 p.sub_((st["m"] * alpha) / (st["v"].sqrt() + eps))
@@ -99,6 +116,34 @@ class KerasAdam(torch.optim.Optimizer):
                     kept.copy_(new.to(kept.device))
                     g["step_dev"] = kept
                 g.pop("step_host", None)   # (state dicts written before the single-counter change)
+
+
+_PENALTY_WS = {}
+
+
+def l2_penalty(params, coefficients) -> torch.Tensor:
+    """``sum_k coefficients[k] * sum(params[k] ** 2)`` as a 0-dim tensor WITHOUT a gradient: the value of the keras l2 penalty a
+    step reports next to its cross-entropy (reference ``H2GCN.py:363-367``), one kernel launch for all tensors
+    (``h2gcn_l2_penalty_f32``: fp64 inside a tensor, fp32 across tensors).  GPU fp32 contiguous tensors only."""
+    params, coefficients = list(params), [float(c) for c in coefficients]
+    n = len(params)
+    if n == 0:
+        return torch.zeros(())
+    dev = params[0].device
+    if not all(p.is_cuda and p.device == dev and p.dtype == torch.float32 and p.is_contiguous() for p in params) or n > 16:
+        raise ValueError("l2_penalty: contiguous fp32 tensors on one GPU (at most 16) expected")
+    L = _capi.lib()
+    ws = _PENALTY_WS.get(dev)
+    if ws is None:
+        ws = _PENALTY_WS[dev] = torch.zeros(int(L.h2gcn_l2_penalty_workspace_bytes()) // 8 + 1, dtype=torch.float64, device=dev)
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    arr = C.c_void_p * n
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _capi.check(L.h2gcn_l2_penalty_f32(n, arr(*[p.data_ptr() for p in params]), (C.c_int64 * n)(*[p.numel() for p in params]),
+                                           (C.c_float * n)(*coefficients), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                           ws.numel() * 8, C.c_void_p(stream)))
+    return out
 
 
 class KerasRMSprop(torch.optim.Optimizer):

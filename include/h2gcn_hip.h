@@ -407,6 +407,20 @@ int h2gcn_adam_keras_f32(int32_t n_tensors, float* const* params_dev, const floa
                          float* const* v_dev, const int64_t* sizes, float lr, float beta1, float beta2, float epsilon,
                          const int64_t* step_dev, int64_t step, void* stream);
 
+/* The same step with the keras `regularizers.l2(w)` of the dense kernels (reference h2gcn/models/H2GCN.py:239-240, 247-248) folded
+ * in: l2 is a HOST array of n_tensors coefficients (0 = tensor not regularised; NULL = none) and the update uses
+ * g + 2 * l2 * param as the gradient -- with the roundings of autograd's separate multiply and add, so a run that keeps the
+ * penalty out of the autograd graph and passes it here follows the one that does not bit for bit.  h2gcn_l2_penalty_f32 is the
+ * VALUE of that penalty, sum_k l2[k] * sum(param_k^2) (fp64 inside a tensor, fp32 across tensors in order), for the loss a step
+ * reports (H2GCN.py:363-367): one launch for up to H2GCN_ADAM_MAX_TENSORS tensors.  workspace: h2gcn_l2_penalty_workspace_bytes()
+ * bytes of device memory, 8-byte aligned, ZERO before its first use (the kernel re-arms it); out_dev: one float. */
+int h2gcn_adam_keras_l2_f32(int32_t n_tensors, float* const* params_dev, const float* const* grads_dev, float* const* m_dev,
+                            float* const* v_dev, const int64_t* sizes, const float* l2, float lr, float beta_1, float beta_2,
+                            float epsilon, const int64_t* step_dev, int64_t step, void* stream);
+size_t h2gcn_l2_penalty_workspace_bytes(void);
+int h2gcn_l2_penalty_f32(int32_t n_tensors, const float* const* params_dev, const int64_t* sizes, const float* l2,
+                         float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Row-shard exchange between the GPUs of one node (no counterpart in the reference: it is single-process,
  * single-device -- SURVEY.md 8(e) adds the row partition).  Before a hop aggregation every rank needs the whole

@@ -437,6 +437,26 @@ def test_keras_adam_restores_into_its_existing_state_tensors():
     assert torch.equal(opt.state[p]["m"], saved["state"][0]["m"])
 
 
+def test_entry_point_with_the_l2_penalty_folded_into_adam_follows_the_autograd_run(tmp_path, monkeypatch):
+    """`run_experiments` on Cora: the keras l2 penalty's gradient folded into the optimizer launch + its value from one kernel
+    (default) vs the penalty inside the autograd graph (H2GCN_FUSED_L2=0): same parameters -- hence accuracies -- and losses that
+    agree to the rounding of the penalty's VALUE (fp64 inside a tensor vs torch's fp32 reduction)."""
+    from test_entrypoints import _export_fixture
+    from h2gcn_amd import run_experiments
+    data_dir = tmp_path / "data"
+    _export_fixture(load_planetoid_golden("cora"), data_dir, "ind.cora")
+    stats = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("H2GCN_FUSED_L2", fused)
+        args = run_experiments.main(["H2GCN", "planetoid", "--dataset", "ind.cora", "--dataset_path", str(data_dir), "--epochs", "25",
+                                     "--random_seed", "7", "--network_setup", "M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", "--no_hipgraph"])
+        stats[fused] = {k: float(v) for k, v in args.objects["epoch_stats"].items() if k != "monitor"}
+    for k in ("train_acc", "val_acc", "test_accuracy", "test_loss"):
+        assert stats["1"][k] == stats["0"][k], (k, stats)
+    for k in ("train_loss", "val_loss"):
+        assert abs(stats["1"][k] - stats["0"][k]) <= 2e-6 * abs(stats["0"][k]), (k, stats)
+
+
 def test_propagation_reuse_is_off_when_a_dropout_precedes_the_propagation(tmp_path):
     g, data, tensors, setup, model = _setup(tmp_path, "D0.5-M64-R-T1-G-V-T2-G-V-C1-C2-D0.5-MO")
     assert not model.reuse_propagation

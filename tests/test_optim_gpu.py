@@ -123,3 +123,39 @@ def test_host_step_argument_is_the_device_counter_by_another_route():
     for t in range(1, 4):
         want, m, v = ok.keras_adam_step(want, g, m, v, t, lr=0.01)
     assert np.abs(outs[0] - want).max() <= 2e-6 * np.abs(want).max()
+
+
+def test_l2_folded_into_the_step_equals_autograd_accumulation_bit_for_bit():
+    """KerasAdam.set_l2: the update uses p.grad + 2 * l2 * p -- with the roundings autograd makes when the keras penalty
+    l2 * sum(p ** 2) is part of the loss (a multiply, then an add into .grad) -- so keeping the penalty out of the graph changes
+    no bit of the trajectory.  l2_penalty: the penalty's value in one launch."""
+    from h2gcn_amd.optim import KerasAdam, l2_penalty
+    shapes = [(1433, 64), (448, 7), (7,)]
+    host = _params(shapes, 5)
+    l2 = 5e-4
+    a = [torch.nn.Parameter(torch.from_numpy(h.copy()).to(DEV)) for h in host]     # penalty through autograd
+    b = [torch.nn.Parameter(torch.from_numpy(h.copy()).to(DEV)) for h in host]     # penalty folded into the step
+    opt_a, opt_b = KerasAdam(a, lr=0.01), KerasAdam(b, lr=0.01)
+    opt_b.set_l2(b[:2], l2)                                                        # the bias is not regularised
+    rng = np.random.default_rng(6)
+    for t in range(8):
+        targets = [torch.from_numpy(rng.normal(size=h.shape).astype(np.float32)).to(DEV) for h in host]
+        for ps, opt, fold in ((a, opt_a, False), (b, opt_b, True)):
+            opt.zero_grad(set_to_none=True)
+            data = sum(((p - tg) ** 2).mean() for p, tg in zip(ps, targets))
+            reg = sum(l2 * (p ** 2).sum() for p in ps[:2])
+            (data if fold else data + reg).backward()
+            opt.step()
+        for pa, pb in zip(a, b):
+            assert torch.equal(pa, pb), t
+    want = sum(l2 * float((p.detach().double() ** 2).sum()) for p in b[:2])
+    got = float(l2_penalty([p.detach() for p in b[:2]], [l2, l2]))
+    assert abs(got - want) <= 2e-6 * want
+    assert float(l2_penalty([p.detach() for p in b[:2]], [l2, l2])) == got          # the workspace re-arms itself
+    # CPU parameters take the formula path with the same fold
+    c = [torch.nn.Parameter(torch.from_numpy(host[0].copy()))]
+    oc = KerasAdam(c, lr=0.01)
+    oc.set_l2(c, l2)
+    c[0].grad = torch.zeros_like(c[0])
+    oc.step()
+    assert not torch.equal(c[0].detach(), torch.from_numpy(host[0]))                 # a zero data gradient still moves a regularised weight
