@@ -16,7 +16,7 @@ while "--used-in" in argv:
     j = i + 1
     while j < len(argv) and not argv[j].startswith("-"):
         for line in Path(argv[j]).read_text().splitlines():
-            m = re.search(r"spmm_hops_kernel<(\d+), (\d+), (true|false), (true|false), (true|false), (true|false), (true|false), (true|false), (\d+)>", line)
+            m = re.search(r"spmm_hops_kernel<(\d+), (\d+), (true|false), (true|false), (true|false), (true|false), (true|false), (true|false), (\d+)(?:, (true|false))?>", line)
             if m:
                 key = tuple("1" if v == "true" else "0" if v in ("false", None) else v for v in m.groups())
                 used.setdefault(key, []).append(f"{Path(argv[j]).name}: {' '.join(line.split()[-2:])}")
