@@ -213,3 +213,24 @@ def test_synthetic_shape_through_the_entry_point(capsys):
     assert args.objects["tensors"]["adj_hops"].n_rows == 170_000
     out = capsys.readouterr().out
     assert "synthetic shape arxiv" in out and "Epoch: 0006" in out
+
+
+def test_bench_without_a_gpu_or_with_too_few_prints_one_error_line():
+    """`python bench.py --gpus N` where N GPUs are not there (here: none): ONE JSON line with "error", exit code 2, no traceback --
+    what the driver's plain `--gpus N` command gets instead of an argument error.  (The ranks are launched by bench.py itself
+    when they are: tests/test_multirank_gpu.py::test_bench_plain_launch_spawns_its_own_ranks.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    ROOT = Path(__file__).resolve().parents[1]
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 4:
+        pytest.skip("a 4-GPU node would run this")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "H2GCN_SHARE_GPU")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--steps", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2 and "Traceback" not in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["n_gpus"] == 4 and "GPU" in line["error"]

@@ -50,3 +50,19 @@ def test_features_identical_and_uniform():
     assert np.array_equal(a, b) and a.dtype == np.float32
     assert -1 <= a.min() and a.max() < 1 and abs(a.mean()) < 0.02
     assert np.array_equal(synth.synth_features_np(128, 125, 0, 300)[10:210], a)
+
+
+def test_mixed_class_shapes_are_what_their_names_say():
+    """The round-4 shapes (dispatch by segment class): h2gcn_like = a sparse hop next to a dense one, products_tail = products'
+    |V| and |E| with degrees from 1, bimodal = short rows scattered among medium ones.  Degree sequences only (cheap, deterministic)."""
+    like = synth.hop_degrees(synth.SHAPES["h2gcn_like"])
+    assert abs(int(like[0].sum()) - 16_000_000) < 0.01 * 16_000_000 and abs(int(like[1].sum()) - 200_000_000) < 0.01 * 200_000_000
+    assert (like[0] <= 16).mean() > 0.85 and (like[1] <= 16).mean() < 0.15 and like[0][like[0] > 0].min() == 1
+    tail = synth.hop_degrees(synth.SHAPES["products_tail"])
+    for d in tail:
+        assert abs(int(d.sum()) - 120_000_000) < 0.01 * 120_000_000 and d[d > 0].min() == 1
+        assert (d < 16).mean() >= 0.40 and d[d <= 16].sum() / d.sum() < 0.1 and (d >= 256).mean() > 0.02
+    bi = synth.hop_degrees(synth.SHAPES["bimodal"])[0]
+    assert 0.55 < (bi <= 16).mean() < 0.65 and 0.3 < bi[bi <= 16].sum() / bi.sum() < 0.37 and 17.0 < bi.mean() < 18.5
+    assert np.array_equal(bi, synth.hop_degrees(synth.SHAPES["bimodal"])[0])           # identical on every rank
+    assert np.array_equal(synth.hop_degrees(synth.SHAPES["products"])[0], synth.synth_degrees(2_400_000, 120_000_000, synth.SEED_A1, 2_400_000))
