@@ -72,6 +72,7 @@ EXPORTED_SYMBOLS = (
     "h2gcn_xchg_allgather_begin",
     "h2gcn_xchg_allgather_post",
     "h2gcn_xchg_allgather_pull",
+    "h2gcn_xchg_allgather_pull_rows",
     "h2gcn_xchg_allgather_end",
     "h2gcn_xchg_reduce_scatter_begin",
     "h2gcn_xchg_reduce_scatter_end",
@@ -245,6 +246,9 @@ def lib() -> C.CDLL:
     L.h2gcn_xchg_allgather_post.argtypes = L.h2gcn_xchg_allgather_begin.argtypes
     L.h2gcn_xchg_allgather_pull.restype = C.c_int
     L.h2gcn_xchg_allgather_pull.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int32, C.c_void_p]
+    if hasattr(L, "h2gcn_xchg_allgather_pull_rows"):
+        L.h2gcn_xchg_allgather_pull_rows.restype = C.c_int
+        L.h2gcn_xchg_allgather_pull_rows.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.h2gcn_xchg_allgather_end.restype = C.c_int
     L.h2gcn_xchg_allgather_end.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.h2gcn_xchg_reduce_scatter_begin.restype = C.c_int

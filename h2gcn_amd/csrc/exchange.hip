@@ -219,6 +219,69 @@ __global__ __launch_bounds__(kPullThreads) void pull_kernel(PeerTable peers, con
     }
 }
 
+
+// Halo pull (copy-kernel mode): instead of a peer's whole shard, only the rows of it this rank's hop matrices really name
+// (`halo.rows[q]`: ascending LOCAL row ids of peer q, `halo.count[q]` of them).  On the synthetic shapes and on any
+// products-like 2-hop ring that is every row and the dense pull is used; on graphs with locality -- a row block of Cora names
+// 71 % of the remote rows at P = 8, its 1-hop ring alone 32 % -- it is what actually has to cross the links.  Same protocol as
+// pull_kernel (flag wait, device-side sequence counters, last-workgroup ticket); rows not listed are left untouched in `full`
+// (nothing reads them).  width % 4 == 0 (16-byte pieces).
+struct HaloTable {
+    const int32_t* rows[kMaxWorld];
+    int64_t count[kMaxWorld];
+};
+
+__global__ __launch_bounds__(kPullThreads) void pull_rows_kernel(PeerTable peers, HaloTable halo, const uint32_t* my_flags, int world, int rank,
+                                                                 int channel, uint32_t* pull_seq_dev, unsigned int* pull_done,
+                                                                 size_t slot_bytes, int64_t rows_per_rank, int width, char* full,
+                                                                 long long timeout_ticks, int* err) {
+    const int pi = blockIdx.x / kPullBlocksPerPeer;
+    const int sub = blockIdx.x - pi * kPullBlocksPerPeer;
+    const int q = pi < rank ? pi : pi + 1;
+    const uint32_t seq = __hip_atomic_load(pull_seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const size_t slot_off = ((size_t)channel * 2 + (seq & 1u)) * slot_bytes;
+    const int32_t* __restrict__ rows = halo.rows[q];
+    const int64_t w4 = width / 4, units = halo.count[q] * w4;
+    const int64_t stride = (int64_t)kPullBlocksPerPeer * kPullThreads;
+    __shared__ int ok;
+    if (threadIdx.x == 0) ok = wait_flag(my_flags + channel * kMaxWorld + q, seq, timeout_ticks, err) ? 1 : 0;
+    __syncthreads();
+    u32x4* __restrict__ d = reinterpret_cast<u32x4*>(full + (size_t)q * (size_t)rows_per_rank * (size_t)width * 4);
+    if (!ok) {  // timed out: poison the rows that were to arrive
+        const u32x4 nan = {0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u};
+        for (int64_t u = (int64_t)sub * kPullThreads + threadIdx.x; u < units; u += stride) d[(int64_t)rows[u / w4] * w4 + u % w4] = nan;
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        const u32x4* __restrict__ s = reinterpret_cast<const u32x4*>(peers.data[q] + slot_off);
+        int64_t u = (int64_t)sub * kPullThreads + threadIdx.x;
+        for (; u + 3 * stride < units; u += 4 * stride) {  // 4 independent 16-B loads in flight per lane
+            int64_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t uk = u + k * stride;
+                o[k] = (int64_t)rows[uk / w4] * w4 + uk % w4;
+            }
+            const u32x4 a = __builtin_nontemporal_load(s + o[0]);
+            const u32x4 b = __builtin_nontemporal_load(s + o[1]);
+            const u32x4 c = __builtin_nontemporal_load(s + o[2]);
+            const u32x4 e = __builtin_nontemporal_load(s + o[3]);
+            d[o[0]] = a;
+            d[o[1]] = b;
+            d[o[2]] = c;
+            d[o[3]] = e;
+        }
+        for (; u < units; u += stride) {
+            const int64_t o = (int64_t)rows[u / w4] * w4 + u % w4;
+            d[o] = __builtin_nontemporal_load(s + o);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(pull_done, 1u) == gridDim.x - 1) {
+        __hip_atomic_store(pull_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pull_seq_dev, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------------
@@ -275,8 +338,20 @@ void release(h2gcn_xchg* x) {
 
 // Pull `bytes` from every peer q -- its exported memory at offset `src_off` -- into dst + q * bytes, after the peer has
 // announced sequence number `seq` on `channel`; records this channel's pull events.
-int issue_pulls(h2gcn_xchg* x, int channel, uint32_t seq, size_t extra_off, size_t bytes, char* dst) {
-    if (x->mode == H2GCN_XCHG_COPY_KERNEL) {
+int issue_pulls(h2gcn_xchg* x, int channel, uint32_t seq, size_t extra_off, size_t bytes, char* dst, const HaloTable* halo = nullptr,
+                int64_t rows_per_rank = 0, int width = 0) {
+    if (x->mode == H2GCN_XCHG_COPY_KERNEL && halo) {
+        hipStream_t cs = x->streams[x->rank];
+        H2GCN_HIP_TRY(hipStreamWaitEvent(cs, x->fence[channel], 0));
+        hipLaunchKernelGGL(pull_rows_kernel, dim3((x->world - 1) * kPullBlocksPerPeer), dim3(kPullThreads), 0, cs, x->peers, *halo,
+                           (const uint32_t*)x->flags, x->world, x->rank, channel, x->seq_dev + kMaxChannels + channel,
+                           (unsigned int*)(x->seq_dev + 2 * kMaxChannels + channel), x->slot_bytes, rows_per_rank, width, dst,
+                           x->timeout_ticks, x->err);
+        H2GCN_HIP_TRY(hipGetLastError());
+        const size_t ei = (size_t)channel * x->world + x->rank;
+        H2GCN_HIP_TRY(hipEventRecord(x->pulled[ei], cs));
+        x->pulled_valid[ei] = 1;
+    } else if (x->mode == H2GCN_XCHG_COPY_KERNEL) {
         hipStream_t cs = x->streams[x->rank];
         H2GCN_HIP_TRY(hipStreamWaitEvent(cs, x->fence[channel], 0));
         hipLaunchKernelGGL(pull_kernel, dim3((x->world - 1) * kPullBlocksPerPeer), dim3(kPullThreads), 0, cs, x->peers,
@@ -452,7 +527,8 @@ int h2gcn_xchg_connect(h2gcn_xchg_t* x, const void* blobs) {
 }
 
 static int allgather_impl(h2gcn_xchg_t* x, int channel, const float* src, int64_t ld_src, int64_t rows,
-                          int64_t rows_per_rank, int32_t width, float* full, void* stream_v, bool do_post, bool do_pull) {
+                          int64_t rows_per_rank, int32_t width, float* full, void* stream_v, bool do_post, bool do_pull,
+                          const HaloTable* halo = nullptr) {
     try {
         if (!x) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is NULL");
         if (!x->connected) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is not connected");
@@ -469,7 +545,7 @@ static int allgather_impl(h2gcn_xchg_t* x, int channel, const float* src, int64_
         hipStream_t stream = (hipStream_t)stream_v;
         if (!do_post) {  // second half of a split begin: the pulls of what allgather_post staged and announced
             if (x->world == 1 || bytes == 0) return H2GCN_OK;
-            return issue_pulls(x, channel, x->seq[channel], 0, bytes, (char*)full);
+            return issue_pulls(x, channel, x->seq[channel], 0, bytes, (char*)full, halo, rows_per_rank, width);
         }
         const uint32_t seq = ++x->seq[channel];   // host mirror (copy-engine mode; copy-kernel mode counts on the device)
         const SeqRef sr = seq_ref(x, channel, seq);
@@ -525,6 +601,29 @@ int h2gcn_xchg_allgather_pull(h2gcn_xchg_t* x, int channel, int64_t rows_per_ran
     x->open_channel[channel] = 0;  // allgather_impl re-checks "not open"
     const int st = allgather_impl(x, channel, nullptr, width, 0, rows_per_rank, width, full, nullptr, false, true);
     x->open_channel[channel] = st == H2GCN_OK ? 1 : 3;  // a failed pull leaves the channel "posted": it can be retried
+    return st;
+}
+
+int h2gcn_xchg_allgather_pull_rows(h2gcn_xchg_t* x, int channel, int64_t rows_per_rank, int32_t width, float* full,
+                                   const int32_t* const* rows_dev, const int64_t* counts) {
+    if (!x) return fail(H2GCN_ERR_INVALID_ARGUMENT, "exchange is NULL");
+    if (channel < 0 || channel >= x->n_channels) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d outside 0..%d", channel, x->n_channels - 1);
+    if (x->mode != H2GCN_XCHG_COPY_KERNEL) return fail(H2GCN_ERR_INVALID_ARGUMENT, "halo pulls exist in copy-kernel mode only");
+    if (width < 4 || width % 4 != 0 || (reinterpret_cast<uintptr_t>(full) & 15u)) return fail(H2GCN_ERR_INVALID_ARGUMENT, "halo pulls move 16-byte pieces: width %d, full %p", width, (void*)full);
+    if (!rows_dev || !counts) return fail(H2GCN_ERR_INVALID_ARGUMENT, "NULL row table");
+    if (x->open_channel[channel] != 3) return fail(H2GCN_ERR_INVALID_ARGUMENT, "channel %d: allgather_pull_rows without allgather_post", channel);
+    HaloTable halo;
+    memset(&halo, 0, sizeof(halo));
+    for (int q = 0; q < x->world; ++q) {
+        if (q == x->rank) continue;
+        if (counts[q] < 0 || counts[q] > rows_per_rank || (counts[q] > 0 && !rows_dev[q]))
+            return fail(H2GCN_ERR_INVALID_ARGUMENT, "halo of peer %d: %lld rows (shard height %lld) or a NULL list", q, (long long)counts[q], (long long)rows_per_rank);
+        halo.rows[q] = rows_dev[q];
+        halo.count[q] = counts[q];
+    }
+    x->open_channel[channel] = 0;  // allgather_impl re-checks "not open"
+    const int st = allgather_impl(x, channel, nullptr, width, 0, rows_per_rank, width, full, nullptr, false, true, &halo);
+    x->open_channel[channel] = st == H2GCN_OK ? 1 : 3;
     return st;
 }
 

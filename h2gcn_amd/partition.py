@@ -247,10 +247,20 @@ class IpcExchange:
                 self._handle, int(channel), C.c_void_p(x_shard.data_ptr()), x_shard.stride(0) if x_shard.shape[0] > 0 else w,
                 int(x_shard.shape[0]), int(rows_per_rank), w, C.c_void_p(full.data_ptr()), C.c_void_p(stream)))
 
-    def pull(self, channel: int, full: torch.Tensor, rows_per_rank: int) -> None:
+    def pull(self, channel: int, full: torch.Tensor, rows_per_rank: int, halo=None) -> None:
+        """Issue the pulls of a posted channel.  ``halo``: per peer an ascending int32 tensor of the LOCAL rows of that peer's
+        shard to fetch (``None`` / missing = nothing from that peer is listed); only those rows land in ``full``
+        (``h2gcn_xchg_allgather_pull_rows``; copy-kernel mode, width a multiple of 4).  Default: whole shards."""
+        C = self._C
         with torch.cuda.device(self.device):
-            self._capi.check(self._capi.lib().h2gcn_xchg_allgather_pull(self._handle, int(channel), int(rows_per_rank),
-                                                                        int(full.shape[1]), self._C.c_void_p(full.data_ptr())))
+            if halo is None:
+                self._capi.check(self._capi.lib().h2gcn_xchg_allgather_pull(self._handle, int(channel), int(rows_per_rank),
+                                                                            int(full.shape[1]), C.c_void_p(full.data_ptr())))
+                return
+            ptrs = (C.c_void_p * self.world)(*[(t.data_ptr() if (t is not None and t.numel()) else None) for t in halo])
+            counts = (C.c_int64 * self.world)(*[(int(t.numel()) if t is not None else 0) for t in halo])
+            self._capi.check(self._capi.lib().h2gcn_xchg_allgather_pull_rows(self._handle, int(channel), int(rows_per_rank),
+                                                                             int(full.shape[1]), C.c_void_p(full.data_ptr()), ptrs, counts))
 
     def end(self, channel: int) -> None:
         with torch.cuda.device(self.device):
@@ -333,8 +343,12 @@ class PipelinedHopAggregation:
 
     def __init__(self, plan, n_rows_global: int, d: int, n_chunks, device,
                  group: Optional[dist.ProcessGroup] = None, exchange: str = "allgather",
-                 partition: Optional[RowPartition] = None, ipc_timeout_ms: Optional[int] = None):
-        """``n_chunks``: number of equal feature chunks, or an explicit list of chunk widths summing to ``d``
+                 partition: Optional[RowPartition] = None, ipc_timeout_ms: Optional[int] = None, halo="auto"):
+        """``halo``: fetch from every peer only the rows of the embedding this rank's hop matrices name (``ipc_kernel`` exchange,
+        chunk widths multiples of 4): ``True`` / ``False`` / ``"auto"`` = when those are less than 90 % of the remote rows (real
+        graphs with locality; never the synthetic shapes or a products-like 2-hop ring, where every row is named).  The named rows
+        are exactly the column ids of the plan, so the result cannot differ from the dense exchange.
+        ``n_chunks``: number of equal feature chunks, or an explicit list of chunk widths summing to ``d``
         (e.g. ``[32, 32, 64]``: a narrow first chunk shortens the un-overlapped head of the exchange).
         ``partition``: the row blocks (default: equal blocks).  With unequal blocks the plan's column ids must already
         live in the padded row space (``RowPartition.to_padded``; ``plan.n_cols == world * per``)."""
@@ -344,6 +358,7 @@ class PipelinedHopAggregation:
         self._gather = _all_gather_rows_p2p if exchange == "p2p" else _all_gather_rows
         self.exchange = exchange
         self.ipc = None
+        self.halo, self.halo_ratio = None, 1.0
         if isinstance(n_chunks, (list, tuple)):
             widths = [int(w) for w in n_chunks]
             if sum(widths) != d or min(widths) < 1:
@@ -386,8 +401,34 @@ class PipelinedHopAggregation:
                     raise ValueError("the IPC exchange needs GPU buffers")
                 self.ipc = IpcExchange(self.C, self.per * max(widths) * 4, device, group, mode=exchange[4:],
                                        timeout_ms=self.ipc_timeout_ms)
+            #: per peer the rows to pull (None: dense pulls); halo_ratio = named remote rows / all remote rows
+            env = os.environ.get("H2GCN_HALO")
+            if env is not None:
+                halo = {"0": False, "1": True}.get(env, halo)
+            if halo and exchange == "ipc_kernel" and all(w % 4 == 0 for w in widths) and hasattr(plan, "colidx"):
+                lists, named, remote = self._halo_lists(plan)
+                self.halo_ratio = named / max(remote, 1)
+                if halo is True or self.halo_ratio < 0.9:
+                    self.halo = lists
         #: set to a list to have (start, end) timing-event pairs appended around every SpMM launch
         self.kernel_events = None
+
+    def _halo_lists(self, plan):
+        """Per peer q the ascending LOCAL row ids of q's block that some column id of this rank's hop matrices names (column ids
+        live in the row space the exchange lands in: global for equal blocks, padded otherwise)."""
+        cols = torch.unique(torch.cat([c.to(torch.int64) for c in plan.colidx])) if sum(c.numel() for c in plan.colidx) else torch.zeros(0, dtype=torch.int64, device=self.device)
+        lists, named, remote = [], 0, 0
+        for q in range(self.world):
+            q0, q1 = self.partition.rows(q)
+            base = q * self.per                       # where q's rows start in the landing space (== q0 for equal blocks)
+            if q == self.rank:
+                lists.append(None)
+                continue
+            sel = cols[(cols >= base) & (cols < base + (q1 - q0))] - base
+            lists.append(sel.to(torch.int32).contiguous())
+            named += int(sel.numel())
+            remote += q1 - q0
+        return lists, named, remote
 
     def close(self) -> None:
         """Collective (when the IPC exchange is in use): release the exported buffers."""
@@ -414,7 +455,7 @@ class PipelinedHopAggregation:
             for c in range(self.C):
                 self.ipc.begin(c, self.send[c], self.full[c], self.per, pull=False)
             for c in range(self.C):
-                self.ipc.pull(c, self.full[c], self.per)
+                self.ipc.pull(c, self.full[c], self.per, halo=self.halo)
             for c in range(self.C):
                 self.ipc.end(c)
         else:
@@ -428,7 +469,7 @@ class PipelinedHopAggregation:
         n_local = self.r1 - self.r0
         if self.ipc is not None:
             self.ipc.begin(c, x_chunk, self.full[c], self.per, pull=False)
-            self.ipc.pull(c, self.full[c], self.per)
+            self.ipc.pull(c, self.full[c], self.per, halo=self.halo)
         elif not self.use_streams:
             self.send[c][:n_local].copy_(x_chunk)
             self._gather(self.full[c], self.send[c], self.group)
@@ -485,7 +526,7 @@ class PipelinedHopAggregation:
             for c in range(self.C):
                 self.ipc.begin(c, x_local[:, cols[c]], self.full[c], self.per, pull=False)
             for c in range(self.C):
-                self.ipc.pull(c, self.full[c], self.per)
+                self.ipc.pull(c, self.full[c], self.per, halo=self.halo)
             for c in range(self.C):
                 self.ipc.end(c)
                 self._spmm(self.full[c][: self.n_src], out[:, :, cols[c]], hops)

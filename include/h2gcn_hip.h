@@ -475,6 +475,12 @@ int h2gcn_xchg_allgather_begin(h2gcn_xchg_t* x, int channel, const float* src_de
 int h2gcn_xchg_allgather_post(h2gcn_xchg_t* x, int channel, const float* src_dev, int64_t ld_src, int64_t rows,
                               int64_t rows_per_rank, int32_t width, float* full_dev, void* stream);
 int h2gcn_xchg_allgather_pull(h2gcn_xchg_t* x, int channel, int64_t rows_per_rank, int32_t width, float* full_dev);
+/* Halo form of the pull (copy-kernel mode, width % 4 == 0): from peer q only the rows rows_dev[q][0 .. counts[q]) (ascending LOCAL
+ * row ids of q's shard, int32, device memory; rows_dev / counts are HOST arrays of `world` entries, the own rank's is ignored) -- the
+ * rows of the embedding this rank's hop matrices really name.  Rows not listed stay untouched in full_dev.  Same protocol, same
+ * allgather_end.  Dense pulls remain the right thing whenever (nearly) every row is named: the synthetic shapes, products-like 2-hop rings. */
+int h2gcn_xchg_allgather_pull_rows(h2gcn_xchg_t* x, int channel, int64_t rows_per_rank, int32_t width, float* full_dev,
+                                   const int32_t* const* rows_dev, const int64_t* counts);
 /* Make `stream` wait (device-side, no host block) until every shard of `channel` has landed in full_dev. */
 int h2gcn_xchg_allgather_end(h2gcn_xchg_t* x, int channel, void* stream);
 /*
