@@ -77,8 +77,9 @@ struct LongList {
 };
 
 struct ClassLists {   // rows (int32, ascending) of the short and of the medium bin of one operand / hop selection
-    DeviceBuf short_dev, med_dev;
+    DeviceBuf short_dev, med_dev;   // allocated only once a launch decides to be list-driven (`built`)
     int64_t n_short = 0, nnz_short = 0, n_med = 0;
+    bool built = false;
     ClassLists() = default;
     ClassLists(ClassLists&&) noexcept = default;
 };
@@ -177,61 +178,86 @@ void collect_segment_lengths(const std::vector<int64_t>& rowptr, int64_t n_rows,
 
 // The short and medium bins of a launch (cached in the plan): forward -- hop `k`'s rows by the class of their segment;
 // adjoint -- the rows whose segments of every hop in `mask` are short, and the rows that are neither that nor contain a
-// long segment (those belong to the long list).
-int get_class_lists(const h2gcn_plan* plan, bool adjoint, int k, uint32_t mask, const ClassLists** out) {
+// long segment (those belong to the long list).  The COUNTS (what the schedule is decided from) are computed on first use;
+// the device lists only when `build` is set, i.e. once a launch really is list-driven -- a products-sized operand whose
+// launches stay on the tile walk never pays the 4 bytes per row and class.
+int get_class_lists(const h2gcn_plan* plan, bool adjoint, int k, uint32_t mask, bool build, const ClassLists** out) {
     *out = nullptr;
     const std::vector<HopOperand>& ops = adjoint ? plan->adj : plan->fwd;
     const int64_t n_rows = adjoint ? plan->n_cols : plan->n_rows;
     if (plan->short_max < 0 || n_rows > 0x7fffffffLL) return H2GCN_OK;
     const uint64_t key = adjoint ? ((uint64_t)mask | (1ull << 32)) : ((uint64_t)k | (1ull << 40));
+    const int sm = plan->short_max;
     std::lock_guard<std::mutex> lock(plan->mu);
     auto it = plan->class_cache.find(key);
-    if (it == plan->class_cache.end()) {
-        std::vector<int32_t> h_short, h_med;
-        int64_t nnz = 0;
-        const int sm = plan->short_max;
-        if (!adjoint) {
-            const std::vector<uint8_t>& len = ops[k].len8;
-            const std::vector<int64_t>& longs = ops[k].long_rows;   // ascending
-            h_short.reserve((size_t)ops[k].n_short);
-            size_t li = 0;
-            for (int64_t r = 0; r < n_rows; ++r) {
-                while (li < longs.size() && longs[li] < r) ++li;
-                const bool is_long = li < longs.size() && longs[li] == r;
-                if (len[(size_t)r] <= sm) { h_short.push_back((int32_t)r); nnz += len[(size_t)r]; }
-                else if (!is_long) h_med.push_back((int32_t)r);
+    std::vector<const uint8_t*> sel;        // adjoint: the selected operands' segment lengths
+    std::vector<uint8_t> any_long;
+    auto prepare_adjoint = [&]() {
+        any_long.assign((size_t)n_rows, 0);
+        for (int h = 0; h < plan->n_hops; ++h)
+            if (mask & (1u << h)) {
+                sel.push_back(ops[h].len8.data());
+                for (int64_t r : ops[h].long_rows) any_long[(size_t)r] = 1;
             }
+    };
+    if (it == plan->class_cache.end()) {
+        ClassLists fresh;
+        if (!adjoint) {
+            fresh.n_short = ops[k].n_short;
+            fresh.nnz_short = ops[k].nnz_short;
+            fresh.n_med = n_rows - ops[k].n_short - (int64_t)ops[k].long_rows.size();
         } else {
-            std::vector<const uint8_t*> sel;
-            std::vector<uint8_t> any_long((size_t)n_rows, 0);
-            for (int h = 0; h < plan->n_hops; ++h)
-                if (mask & (1u << h)) {
-                    sel.push_back(ops[h].len8.data());
-                    for (int64_t r : ops[h].long_rows) any_long[(size_t)r] = 1;
-                }
+            prepare_adjoint();
             for (int64_t r = 0; r < n_rows; ++r) {
                 bool all = true;
                 int64_t z = 0;
                 for (const uint8_t* l : sel) { all = all && l[r] <= sm; z += l[r]; }
-                if (all) { h_short.push_back((int32_t)r); nnz += z; }
-                else if (!any_long[(size_t)r]) h_med.push_back((int32_t)r);
+                if (all) { ++fresh.n_short; fresh.nnz_short += z; }
+                else if (!any_long[(size_t)r]) ++fresh.n_med;
             }
-        }
-        ClassLists fresh;
-        fresh.n_short = (int64_t)h_short.size();
-        fresh.nnz_short = nnz;
-        fresh.n_med = (int64_t)h_med.size();
-        if (fresh.n_short > 0) {
-            H2GCN_HIP_TRY(hipMalloc(&fresh.short_dev.p, h_short.size() * sizeof(int32_t)));
-            H2GCN_HIP_TRY(hipMemcpy(fresh.short_dev.p, h_short.data(), h_short.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        }
-        if (fresh.n_med > 0) {
-            H2GCN_HIP_TRY(hipMalloc(&fresh.med_dev.p, h_med.size() * sizeof(int32_t)));
-            H2GCN_HIP_TRY(hipMemcpy(fresh.med_dev.p, h_med.data(), h_med.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
         it = plan->class_cache.emplace(key, std::move(fresh)).first;
     }
-    *out = &it->second;
+    ClassLists& cl = it->second;
+    if (build && !cl.built) {
+        std::vector<int32_t> h_short, h_med;
+        h_short.reserve((size_t)cl.n_short);
+        h_med.reserve((size_t)cl.n_med);
+        if (!adjoint) {
+            const std::vector<uint8_t>& len = ops[k].len8;
+            const std::vector<int64_t>& longs = ops[k].long_rows;   // ascending
+            size_t li = 0;
+            for (int64_t r = 0; r < n_rows; ++r) {
+                while (li < longs.size() && longs[li] < r) ++li;
+                const bool is_long = li < longs.size() && longs[li] == r;
+                if (len[(size_t)r] <= sm) h_short.push_back((int32_t)r);
+                else if (!is_long) h_med.push_back((int32_t)r);
+            }
+        } else {
+            if (sel.empty()) prepare_adjoint();
+            for (int64_t r = 0; r < n_rows; ++r) {
+                bool all = true;
+                for (const uint8_t* l : sel) all = all && l[r] <= sm;
+                if (all) h_short.push_back((int32_t)r);
+                else if (!any_long[(size_t)r]) h_med.push_back((int32_t)r);
+            }
+        }
+        DeviceBuf d_short, d_med;
+        if (!h_short.empty()) {
+            H2GCN_HIP_TRY(hipMalloc(&d_short.p, h_short.size() * sizeof(int32_t)));
+            H2GCN_HIP_TRY(hipMemcpy(d_short.p, h_short.data(), h_short.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        if (!h_med.empty()) {
+            H2GCN_HIP_TRY(hipMalloc(&d_med.p, h_med.size() * sizeof(int32_t)));
+            H2GCN_HIP_TRY(hipMemcpy(d_med.p, h_med.data(), h_med.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        cl.short_dev.p = d_short.p;
+        d_short.p = nullptr;
+        cl.med_dev.p = d_med.p;
+        d_med.p = nullptr;
+        cl.built = true;
+    }
+    *out = &cl;
     return H2GCN_OK;
 }
 
@@ -356,7 +382,7 @@ struct LaunchShape {
 };
 
 LaunchShape shape_of(const h2gcn_plan* plan, uint32_t mask, bool adjoint);
-int fill_short(const h2gcn_plan* plan, uint32_t mask, bool adjoint, LaunchShape& sh);
+int fill_short(const h2gcn_plan* plan, uint32_t mask, bool adjoint, LaunchShape& sh, bool build_lists = false);
 
 // Slice width of the slice-major scratch copy this launch should gather from (see repack_slice_major_kernel);
 // 0 = gather from the source as it is.  Because every slice width >= 64 produces the same summation tree, the copy
@@ -434,7 +460,7 @@ Schedule decide(int variant, bool exact_ok, int d, int rows_per_wave, int n_sel,
 }
 
 template <bool SUM>
-int launch(LaunchParams& p, const h2gcn_plan* plan, const LaunchShape& sh, bool off32, int forced_slice, hipStream_t stream) {
+int launch(LaunchParams& p, const h2gcn_plan* plan, uint32_t mask, LaunchShape& sh, bool off32, int forced_slice, hipStream_t stream) {
     using namespace h2gcn;
     // A/B measurements only (profiles/r04_ab_off64_*.txt): run the 64-bit-offset instantiations on an operand that would
     // qualify for 32-bit gather offsets
@@ -455,6 +481,10 @@ int launch(LaunchParams& p, const h2gcn_plan* plan, const LaunchShape& sh, bool 
     p.short_max = -1;
     p.short_groups = p.med_groups = 0;
     if (lists) {
+        // the device lists exist from the first list-driven launch of this selection on (all-hops selections of mixed operands:
+        // from plan creation, so that such launches can be captured into a hipGraph without a warm-up)
+        int st = fill_short(plan, mask, SUM, sh, true);
+        if (st != H2GCN_OK) return st;
         // list-driven launch: short-list workgroups serve 4 waves x 64 entries, medium-list workgroups 4 waves x
         // med_per_wave entries; forward -- one run of workgroups per selected hop and class
         int64_t n_listed = 0, n_med = 0, longest = 0;
@@ -768,12 +798,18 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
             int st = get_long_list(plan.get(), false, all, &unused_p, &unused_n);
             if (st == H2GCN_OK && plan->has_transpose) st = get_long_list(plan.get(), true, all, &unused_p, &unused_n);
             if (st != H2GCN_OK) return st;
-            // ... and the binned short segments of that selection (every forward hop's list; the all-hops adjoint list)
+            // ... and, for MIXED operands (the all-hops launch will be list-driven at the usual widths), the segment-class lists
+            // of that selection; everything else builds them on the first launch that wants them
+            auto mixed = [&](const LaunchShape& sh_) {
+                return plan->variant == 6 || (plan->variant == 0 && sh_.avg >= 16.0 && sh_.short_frac >= plan->short_min_frac);
+            };
             LaunchShape sh_f = shape_of(plan.get(), all, false);
             if ((st = fill_short(plan.get(), all, false, sh_f)) != H2GCN_OK) return st;
+            if (mixed(sh_f) && (st = fill_short(plan.get(), all, false, sh_f, true)) != H2GCN_OK) return st;
             if (plan->has_transpose) {
                 LaunchShape sh_a = shape_of(plan.get(), all, true);
                 if ((st = fill_short(plan.get(), all, true, sh_a)) != H2GCN_OK) return st;
+                if (mixed(sh_a) && (st = fill_short(plan.get(), all, true, sh_a, true)) != H2GCN_OK) return st;
             }
         }
         *out_plan = plan.release();
@@ -838,7 +874,8 @@ LaunchShape shape_of(const h2gcn_plan* plan, uint32_t mask, bool adjoint) {
 }
 
 // The binned short segments this hop selection can use (lists are built on first use and cached in the plan).
-int fill_short(const h2gcn_plan* plan, uint32_t mask, bool adjoint, LaunchShape& sh) {
+// Shares of the launch's segments / nonzeros in the short class (always), and -- build_lists -- the device lists themselves.
+int fill_short(const h2gcn_plan* plan, uint32_t mask, bool adjoint, LaunchShape& sh, bool build_lists) {
     sh.n_short_lists = 0;
     sh.short_frac = sh.short_nnz_frac = 0.0;
     if (plan->short_max < 0 || sh.n_out <= 0 || sh.n_sel <= 0) return H2GCN_OK;
@@ -848,7 +885,7 @@ int fill_short(const h2gcn_plan* plan, uint32_t mask, bool adjoint, LaunchShape&
         int s = 0;
         for (int k = 0; k < plan->n_hops; ++k) {
             if (!(mask & (1u << k))) continue;
-            int st = get_class_lists(plan, false, k, 0, &cl);
+            int st = get_class_lists(plan, false, k, 0, build_lists, &cl);
             if (st != H2GCN_OK) return st;
             if (!cl) return H2GCN_OK;
             sh.short_list[s] = (const int32_t*)cl->short_dev.p;
@@ -863,7 +900,7 @@ int fill_short(const h2gcn_plan* plan, uint32_t mask, bool adjoint, LaunchShape&
         sh.short_frac = (double)n / ((double)sh.n_out * sh.n_sel);
     } else {
         if (sh.n_sel > h2gcn::kShortSumHops) return H2GCN_OK;
-        int st = get_class_lists(plan, true, 0, mask, &cl);
+        int st = get_class_lists(plan, true, 0, mask, build_lists, &cl);
         if (st != H2GCN_OK) return st;
         if (!cl) return H2GCN_OK;
         sh.short_list[0] = (const int32_t*)cl->short_dev.p;
@@ -1043,7 +1080,7 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
             forced_slice = rs;
         }
         if ((st = fill_short(plan, mask, false, sh)) != H2GCN_OK) return st;
-        return launch<false>(p, plan, sh, off32, forced_slice, (hipStream_t)stream_v);
+        return launch<false>(p, plan, mask, sh, off32, forced_slice, (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_opts_f32");
     }
@@ -1116,7 +1153,7 @@ int h2gcn_spmm_hops_T_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, cons
             forced_slice = rs;
         }
         if ((st = fill_short(plan, mask, true, sh)) != H2GCN_OK) return st;
-        return launch<true>(p, plan, sh, off32, forced_slice, (hipStream_t)stream_v);
+        return launch<true>(p, plan, mask, sh, off32, forced_slice, (hipStream_t)stream_v);
     } catch (...) {
         return fail(H2GCN_ERR_INTERNAL, "unexpected exception in spmm_hops_T_f32");
     }
