@@ -262,13 +262,14 @@ class _FusedPropagation(torch.autograd.Function):
         # temporary of its own (`private_grad`: models.H2GCN sets it when the buffer's sole consumer is a layer whose
         # backward allocates its input gradient, DropoutDense / Dense / Dropout).  Autograd itself gives no such guarantee
         # (a user-supplied `out.backward(G)`, a hook or `retain_grad` on the buffer, a gradient shared with another node),
-        # so the default is a fresh tensor per round plus one `+=` pass.  Also needed: an ordinary dense gradient and the
-        # wave-per-segment regime (the accumulating launch has no short-row variant).
+        # so the default is a fresh tensor per round plus one `+=` pass.  Also needed: an ordinary dense gradient.
         dense = (ctx.private_grad and grad.is_contiguous() and isinstance(plan, HopPlan)
                  and os.environ.get("H2GCN_BACKWARD_IN_PLACE", "1") != "0")
         for k in range(K, 0, -1):
             slot = grad[:, off[k - 1]:off[k - 1] + widths[k - 1]]
-            in_place = dense and plan.schedule(widths[k - 1], ld_src=grad.stride(0), adjoint=True)["segment_walk"] == "wave per segment"
+            # (not where the plain launch would run in the in-tile short-row mode -- short-throughout operands, where that mode is
+            # worth more than the saved pass; list-driven / wave-walk launches lose nothing on the accumulating tile walk)
+            in_place = dense and plan.schedule(widths[k - 1], ld_src=grad.stride(0), adjoint=True)["segment_walk"] != "lane group per segment (short rows)"
             if in_place:
                 g_k = plan.spmm_t(g_k.unflatten(1, (H, widths[k - 1])), out=slot, accumulate=True)
             else:
