@@ -56,6 +56,7 @@ EXPORTED_SYMBOLS = (
     "h2gcn_ring_fill_rows",
     "h2gcn_hop_normalize",
     "h2gcn_hop_normalize_rows",
+    "h2gcn_dropout_dense_small_rows",
     "h2gcn_dropout_dense_workspace_bytes",
     "h2gcn_dropout_dense_f32",
     "h2gcn_dropout_dense_backward_f32",
@@ -202,6 +203,9 @@ def lib() -> C.CDLL:
     L.h2gcn_hop_normalize_rows.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.h2gcn_hop_normalize.restype = C.c_int
     L.h2gcn_hop_normalize.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    if hasattr(L, "h2gcn_dropout_dense_small_rows"):
+        L.h2gcn_dropout_dense_small_rows.restype = C.c_int64
+        L.h2gcn_dropout_dense_small_rows.argtypes = [C.c_int64]
     L.h2gcn_dropout_dense_workspace_bytes.restype = C.c_size_t
     L.h2gcn_dropout_dense_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     L.h2gcn_dropout_dense_f32.restype = C.c_int

@@ -161,6 +161,130 @@ __device__ __forceinline__ f4u apply_mask(f4u v, const MaskKey& mk, int64_t row,
     return v;
 }
 
+
+// ---- small operands (the reference's own datasets: Cora 2 708 rows, citeseer 3 327, syn-products 10 000) -----------------
+// At a few thousand rows the kernels above are one latency chain each -- 7 K-chunks x (fragment fetch, LDS fill, barrier) in
+// a handful of workgroups, plus a weight-packing launch in front: ~18 us per pass on Cora, where a whole training epoch is
+// 0.3 ms (profiles/r04_cora_epoch_kernels.txt: 30 % of it).  Below kSmallRows rows (and C <= 16) three plain VALU kernels
+// serve the forward and dX with the same contract -- same mask generator, same placement of the 1 / keep scale, fp32 FMAs,
+// deterministic -- and the shortest chain each: no packing launch, W^T staged once per workgroup in LDS (12.5 KB on Cora).
+// (dW stays on the matrix-core kernel + its fixed-order reduction: a column-slab walk over all rows in plain code was tried and
+// is slower, 26.7 vs 18.2 us on Cora.)
+constexpr int kSmallCP = 16;   // classes the small kernels keep in registers
+
+// W^T staged in LDS as Wt[c][Kp] (Kp = K rounded up to 4, zero-padded): a lane / thread that owns the column group k .. k+3
+// reads its four weights of class c with ONE 16-byte LDS read, consecutive lanes consecutive addresses (no bank conflicts);
+// straight from memory the same access is a 112-byte-stride gather over W's rows
+__device__ __forceinline__ void stage_wt(const float* __restrict__ W, int K, int C, int Kp, float* __restrict__ wt) {
+    for (int t = threadIdx.x; t < Kp * C; t += kThreads) {
+        const int k = t / C, c = t - k * C;                 // coalesced read of W[k][c]
+        wt[c * Kp + k] = k < K ? W[t] : 0.f;
+    }
+    __syncthreads();
+}
+
+// forward: one wave per row (kSmallRowsPerWave rows in turn); lane l owns the column groups l, l + 64, ...; 16 class partials
+// per lane, folded across the wave
+constexpr int kSmallRowsPerWave = 1;   // (2 / 4 rows per wave: 11-13 / 18-19 us per pass on Cora instead of 8-10: the launch is one wave's chain)
+constexpr int kSmallMaxK = 512;      // forward: two column groups per lane in registers (wider operands: matrix-core kernels)
+template <int MASK>
+__global__ __launch_bounds__(kThreads) void small_fwd_kernel(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int K,
+                                                             const float* __restrict__ W, const float* __restrict__ bias, int C,
+                                                             float inv_keep, uint32_t thr, int mask_on, uint64_t seed,
+                                                             const int64_t* step_dev, float* __restrict__ Y, int64_t ldy) {
+    extern __shared__ float wt[];   // [C][Kp]
+    const int Kp = (K + 3) & ~3;
+    const int lane = threadIdx.x & 63;
+    const MaskKey mk = make_key(seed, step_dev, thr, mask_on, K);
+    const int64_t row0 = ((int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * kSmallRowsPerWave;
+    // this wave's fragments of X first (K <= 512: the groups 4*lane and 256 + 4*lane of each row): their latency runs under the
+    // staging of W
+    f4u a[kSmallRowsPerWave][2];
+#pragma unroll
+    for (int r = 0; r < kSmallRowsPerWave; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) a[r][h] = load_row4(X, ldx, n_rows, K, row0 + r, 256 * h + 4 * lane);
+    stage_wt(W, K, C, Kp, wt);
+#pragma unroll
+    for (int r = 0; r < kSmallRowsPerWave; ++r) {
+        const int64_t row = row0 + r;
+        float acc[kSmallCP];
+#pragma unroll
+        for (int c = 0; c < kSmallCP; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 256 * h + 4 * lane;
+            if (k < K) {
+                const f4u x = apply_mask<MASK>(a[r][h], mk, row, k);
+#pragma unroll
+                for (int c = 0; c < kSmallCP; ++c) {
+                    if (c < C) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wt + c * Kp + k);
+                        acc[c] = fmaf(x[0], w[0], acc[c]);
+                        acc[c] = fmaf(x[1], w[1], acc[c]);
+                        acc[c] = fmaf(x[2], w[2], acc[c]);
+                        acc[c] = fmaf(x[3], w[3], acc[c]);
+                    }
+                }
+            }
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int c = 0; c < kSmallCP; ++c) {
+            if (c < C) {
+                float v = acc[c];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);   // fixed butterfly: deterministic
+                mine = lane == c ? v : mine;
+            }
+        }
+        if (lane < C && row < n_rows) Y[row * ldy + lane] = mine * inv_keep + (bias ? bias[lane] : 0.f);
+    }
+}
+
+// backward, data: one thread per (row, group of four columns)
+template <int MASK>
+__global__ __launch_bounds__(kThreads) void small_dx_kernel(const float* __restrict__ G, int64_t ldg, int64_t n_rows, int K, int C,
+                                                            const float* __restrict__ W, float inv_keep, uint32_t thr, int mask_on,
+                                                            uint64_t seed, const int64_t* step_dev, float* __restrict__ dX, int64_t lddx) {
+    extern __shared__ float wt[];   // [C][Kp]
+    const int Kp = (K + 3) & ~3;
+    const int groups = Kp / 4;
+    stage_wt(W, K, C, Kp, wt);
+    const MaskKey mk = make_key(seed, step_dev, thr, mask_on, K);
+    const int64_t total = n_rows * groups;
+    for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < total; t += (int64_t)gridDim.x * kThreads) {
+        const int64_t row = t / groups;
+        const int k = (int)(t - row * groups) * 4;
+        f32x4 out = {0.f, 0.f, 0.f, 0.f};
+        const float* g = G + row * ldg;
+#pragma unroll
+        for (int c = 0; c < kSmallCP; ++c) {
+            if (c < C) {
+                const float gc = g[c];
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wt + c * Kp + k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[j] = fmaf(gc, w[j], out[j]);
+            }
+        }
+        f4u keep = {inv_keep, inv_keep, inv_keep, inv_keep};
+        keep = apply_mask<MASK>(keep, mk, row, k);        // inv_keep where kept, 0 where dropped
+        float* dst = dX + row * lddx + k;
+        if (k + 4 <= K) {
+            f4u o = {out[0] * keep[0], out[1] * keep[1], out[2] * keep[2], out[3] * keep[3]};
+            *reinterpret_cast<f4u*>(dst) = o;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k + j < K) dst[j] = out[j] * keep[j];
+        }
+    }
+}
+
+int64_t g_small_rows = 32768;   // operands of at most this many rows (and C <= kSmallCP) take the small kernels; 0 = never
+size_t small_lds_bytes(int K, int C) { return (size_t)((K + 3) & ~3) * C * 4; }
+bool small_operand(int64_t n_rows, int K, int C) { return n_rows <= g_small_rows && C <= kSmallCP && K <= kSmallMaxK; }
+
 // ---- forward -------------------------------------------------------------------------------------------------------------
 // One workgroup = 4 waves x 32 rows; a wave owns 2 row tiles x NT column tiles of 16x16 accumulators.  W chunks of 128 rows
 // are double-buffered in LDS (one barrier per chunk).
@@ -490,6 +614,12 @@ int with_nt_mask(int nt, int mask, F&& f) {
 
 extern "C" {
 
+int64_t h2gcn_dropout_dense_small_rows(int64_t rows) {
+    const int64_t old = g_small_rows;
+    if (rows >= 0) g_small_rows = rows;
+    return old;
+}
+
 size_t h2gcn_dropout_dense_workspace_bytes(int64_t n_rows, int32_t k, int32_t c) {
     if (n_rows < 0 || k < 1 || c < 1 || c > 64) return 0;
     return shape_of(n_rows, k, c).total;
@@ -506,6 +636,18 @@ int h2gcn_dropout_dense_f32(const float* X, int64_t ldx, int64_t n_rows, int32_t
     if (!workspace || workspace_bytes < s.total || ((uintptr_t)workspace & 15u))
         return fail(H2GCN_ERR_INVALID_ARGUMENT, "dropout_dense: workspace of %zu bytes (16-byte aligned) needed, got %zu", s.total, workspace_bytes);
     hipStream_t stream = (hipStream_t)stream_v;
+    if (small_operand(n_rows, K, C)) {   // latency-bound operand: one plain kernel, no packing
+        const int64_t rows_per_block = (int64_t)(kThreads / 64) * kSmallRowsPerWave;
+        const unsigned blocks = (unsigned)((n_rows + rows_per_block - 1) / rows_per_block);
+        const size_t lds = small_lds_bytes(K, C);
+        switch (mask_mode(keep_prob)) {
+            case 0: hipLaunchKernelGGL(small_fwd_kernel<0>, dim3(blocks), dim3(kThreads), lds, stream, X, ldx, n_rows, (int)K, W, bias, (int)C, 1.f / keep_prob, keep_threshold(keep_prob), 0, seed, step_dev, Y, ldy); break;
+            case 1: hipLaunchKernelGGL(small_fwd_kernel<1>, dim3(blocks), dim3(kThreads), lds, stream, X, ldx, n_rows, (int)K, W, bias, (int)C, 1.f / keep_prob, keep_threshold(keep_prob), 1, seed, step_dev, Y, ldy); break;
+            default: hipLaunchKernelGGL(small_fwd_kernel<2>, dim3(blocks), dim3(kThreads), lds, stream, X, ldx, n_rows, (int)K, W, bias, (int)C, 1.f / keep_prob, keep_threshold(keep_prob), 1, seed, step_dev, Y, ldy); break;
+        }
+        H2GCN_HIP_TRY(hipGetLastError());
+        return H2GCN_OK;
+    }
     float* wp = (float*)((char*)workspace + s.off_wfwd);
     const int S = lds_stride(s.nt);
     hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(64), dim3(256), 0, stream, W, (int)K, (int)C, s.kpad, S, wp);
@@ -541,6 +683,18 @@ int h2gcn_dropout_dense_backward_f32(const float* X, int64_t ldx, int64_t n_rows
     if (n_rows == 0) {
         if (dW) H2GCN_HIP_TRY(hipMemsetAsync(dW, 0, (size_t)K * C * 4, stream));
         return H2GCN_OK;
+    }
+    if (dX && small_operand(n_rows, K, C)) {   // latency-bound operand (see small_fwd_kernel); dW below, on the matrix cores
+        const int64_t total = n_rows * ((K + 3) / 4);
+        const unsigned blocks = (unsigned)std::min<int64_t>((total + kThreads - 1) / kThreads, 2 * (int64_t)cu_count());   // W^T is staged once per workgroup
+        const size_t lds = small_lds_bytes(K, C);
+        switch (mask_mode(keep_prob)) {
+            case 0: hipLaunchKernelGGL(small_dx_kernel<0>, dim3(blocks), dim3(kThreads), lds, stream, G, ldg, n_rows, (int)K, (int)C, W, inv_keep, thr, 0, seed, step_dev, dX, lddx); break;
+            case 1: hipLaunchKernelGGL(small_dx_kernel<1>, dim3(blocks), dim3(kThreads), lds, stream, G, ldg, n_rows, (int)K, (int)C, W, inv_keep, thr, 1, seed, step_dev, dX, lddx); break;
+            default: hipLaunchKernelGGL(small_dx_kernel<2>, dim3(blocks), dim3(kThreads), lds, stream, G, ldg, n_rows, (int)K, (int)C, W, inv_keep, thr, 1, seed, step_dev, dX, lddx); break;
+        }
+        H2GCN_HIP_TRY(hipGetLastError());
+        dX = nullptr;   // done
     }
     if (dX) {
         float* wtp = (float*)((char*)workspace + s.off_wdx);
