@@ -681,6 +681,7 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
         plan->variant = o.variant;
         if (o.variant == 0) if (const char* e = getenv("H2GCN_VARIANT")) plan->variant = atoi(e);   // experiments through the entry points
         plan->slice_cols = o.slice_cols;
+        if (o.slice_cols == 0) if (const char* e = getenv("H2GCN_SLICE_COLS")) plan->slice_cols = atoi(e);   // experiments through the entry points
         // segment classes: short <= short_max < medium < long_threshold <= long
         plan->short_max = std::min(h2gcn::kShortMax, plan->long_threshold - 1);
         if (const char* e = getenv("H2GCN_SHORT_MIN_FRAC")) plan->short_min_frac = atof(e);   // A/B measurements
