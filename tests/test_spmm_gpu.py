@@ -637,6 +637,33 @@ def test_csr_adaptive_segment_classes_in_one_launch(kinds, d):
     assert np.array_equal(plan.spmm(xo).cpu().numpy(), og.gcn_layer_tree(hops, x[:, : d - 3]))
 
 
+@pytest.mark.parametrize("n,d", [(300_000, 128), (1_200_000, 64)])
+def test_list_driven_launch_at_scale_has_the_bits_of_the_tile_walk(n, d):
+    """Mixed segment classes at a size where the list-driven launch uses everything it has -- hundreds of thousands of listed
+    entries (16 ... 64 per wave), short- and medium-list workgroups interleaved in groups of 8, a partial last workgroup per
+    list, long segments next to them: the WHOLE result (forward, hop subset, adjoint) equals the plain tile walk's bit for bit."""
+    from h2gcn_amd import HopPlan, synth
+
+    device = dev()
+    cfg = dict(n=n, nnz_per_hop=[6 * n, 40 * n], degrees=[dict(sigma=1.0), dict(sigma=1.3)])
+    degs = synth.hop_degrees(cfg, (31, 32))
+    csr = [synth.synth_hop_rows(degs[k], n, (31, 32)[k], 0, n, device) for k in range(2)]
+    args = ([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n)
+    ref = HopPlan(*args, build_transpose=True, variant=3)
+    x = synth.synth_features(d, 33, 0, n, device)
+    w = synth.synth_features(2 * d, 34, 0, n, device).view(n, 2, d)
+    y_ref, dx_ref = ref.spmm(x), ref.spmm_t(w)
+    for variant in (0, 6):
+        plan = HopPlan(*args, build_transpose=True, variant=variant)
+        cls = plan.segment_classes(d)
+        assert cls["listed"] > 0.3 * n and all(h["segments"]["long"] > 0 for h in cls["per_hop"][1:]), cls
+        assert torch.equal(plan.spmm(x), y_ref), variant
+        assert torch.equal(plan.spmm(x, hops=[0]), ref.spmm(x, hops=[0]))
+        assert torch.equal(plan.spmm_t(w), dx_ref), variant     # (the transposed operands have Poisson column counts ~ 6 / 40: the
+        #  all-hops adjoint has no all-short rows and stays on the tile walk; the 1-hop one alone is list-driven or in-tile)
+        assert torch.equal(plan.spmm_t(w[:, :1].contiguous(), hops=[0]), ref.spmm_t(w[:, :1].contiguous(), hops=[0]))
+
+
 def test_cora_one_hop_ring_is_served_by_the_binned_list():
     """The reference's own operands are bimodal (exact-1-hop ring: mean 3.9 nonzeros per row, exact-2-hop ring: 31.9): the
     pooled mean (17.9) used to put the WHOLE launch on the wave walk; now A1's segments are listed and served one lane
