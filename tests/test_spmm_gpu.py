@@ -664,6 +664,40 @@ def test_list_driven_launch_at_scale_has_the_bits_of_the_tile_walk(n, d):
         assert torch.equal(plan.spmm_t(w[:, :1].contiguous(), hops=[0]), ref.spmm_t(w[:, :1].contiguous(), hops=[0]))
 
 
+def test_list_driven_adjoint_at_scale_on_a_symmetric_graph():
+    """Real adjacency rings are symmetric, so the transposed operands have the forward's segment classes: a quarter of the rows of
+    A_1^T and A_2^T are short in BOTH hops and the SUM-mode launch is list-driven as well (rows whose segments of all selected
+    hops are short: one lane group each, partials running on across the hops).  Whole-tensor bit equality with the tile walk."""
+    from h2gcn_amd import HopPlan, synth
+
+    device = dev()
+    n, d = 200_000, 128
+    cfg = dict(n=n, nnz_per_hop=[5 * n, 12 * n], degrees=[dict(sigma=1.0), dict(sigma=1.3)])     # symmetrised: means ~10 and ~24
+    degs = synth.hop_degrees(cfg, (41, 42))
+    csr = []
+    for k in range(2):
+        rp, ci, _ = synth.synth_hop_rows(degs[k], n, (41, 42)[k], 0, n, device)
+        rows = torch.repeat_interleave(torch.arange(n, device=device), rp[1:] - rp[:-1])
+        key = torch.unique(torch.cat([rows * n + ci.long(), ci.long() * n + rows]))        # A + A^T pattern
+        r, c = torch.div(key, n, rounding_mode="floor"), (key % n).to(torch.int32)
+        cnt = torch.bincount(r, minlength=n)
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+        rowptr[1:] = torch.cumsum(cnt, 0)
+        vals = (1.0 / cnt.to(torch.float32))[r] * (1.0 + (c % 7).to(torch.float32) * 0.125)   # not symmetric in value: A^T != A
+        csr.append((rowptr, c.contiguous(), vals.contiguous()))
+    args = ([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n)
+    ref = HopPlan(*args, build_transpose=True, variant=3)
+    x = synth.synth_features(d, 43, 0, n, device)
+    w = synth.synth_features(2 * d, 44, 0, n, device).view(n, 2, d)
+    for variant in (0, 6):
+        plan = HopPlan(*args, build_transpose=True, variant=variant)
+        assert plan.segment_classes(d, adjoint=True)["listed"] > 0.1 * n and plan.segment_classes(d)["listed"] > 0.5 * n
+        assert plan.schedule(d, adjoint=True)["segment_walk"].startswith("lane group per segment (binned")
+        assert torch.equal(plan.spmm_t(w), ref.spmm_t(w)), variant
+        assert torch.equal(plan.spmm(x), ref.spmm(x)), variant
+        assert torch.equal(plan.spmm_t(w[:, 1:].contiguous(), hops=[1]), ref.spmm_t(w[:, 1:].contiguous(), hops=[1]))
+
+
 def test_cora_one_hop_ring_is_served_by_the_binned_list():
     """The reference's own operands are bimodal (exact-1-hop ring: mean 3.9 nonzeros per row, exact-2-hop ring: 31.9): the
     pooled mean (17.9) used to put the WHOLE launch on the wave walk; now A1's segments are listed and served one lane
