@@ -437,7 +437,8 @@ struct Schedule {
 //   * otherwise the wave-per-segment tile walk.
 // (Rounds 2-3 chose ONE walk per launch from the pooled mean alone.)
 Schedule decide(int variant, bool exact_ok, int d, int rows_per_wave, int n_sel, int forced_slice, int64_t n_src_rows,
-                double avg_segment_nnz, bool rows_line_aligned, bool gen, double short_frac, double short_nnz_frac, double short_min_frac) {
+                double avg_segment_nnz, bool rows_line_aligned, bool gen, double short_frac, double short_nnz_frac, double short_min_frac,
+                int64_t n_out_rows) {
     Schedule sc;
     // index prefetch across segments: pays on short segments (+4 % at mean degree 4), costs ~0.4 % on long ones;
     // variant 2 forces it, variant 3 forbids it (bitwise-identical results either way)
@@ -449,7 +450,10 @@ Schedule decide(int variant, bool exact_ok, int d, int rows_per_wave, int n_sel,
     const bool grouped_ok = sc.exact && !sc.scalar128 && !gen && (sc.slice == 64 || sc.slice == 128);   // 4 / 2 lane groups, plain stores
     // variant 5 forces the in-tile short-row mode, variant 6 the list-driven launch (when a short segment exists at all);
     // variants 2 / 3 keep the wave-per-segment walk with / without the index prefetch
-    sc.shortrow = grouped_ok && (variant == 5 || (variant == 0 && avg_segment_nnz < 16.0));
+    // (the in-tile mode is a THROUGHPUT device: below ~50 k output rows a launch is a few waves' dependent chains, a wave takes
+    // one row -- see kWavesToFill -- and a round of the in-tile mode would use one of its G lane groups; such launches are
+    // list-driven instead: citeseer epoch 0.277-0.328 ms in-tile vs 0.256 ms, profiles/r04_ab_work_per_wave.txt)
+    sc.shortrow = grouped_ok && (variant == 5 || (variant == 0 && avg_segment_nnz < 16.0 && n_out_rows >= 4 * kWavesToFill));
     sc.lists = grouped_ok && !sc.shortrow && short_frac > 0.0 && (variant == 6 || (variant == 0 && short_frac >= short_min_frac));
     sc.pipe = sc.pipe && sc.exact && !sc.shortrow && !sc.lists && !gen;
     // shallow load batches (more waves per SIMD) once the gather source is far beyond the caches: in-tile mode always
@@ -471,7 +475,7 @@ int launch(LaunchParams& p, const h2gcn_plan* plan, uint32_t mask, LaunchShape& 
     // general store (bias / ReLU epilogue, element-wise tail of a width that is not a multiple of 4): dedicated instantiations
     const bool gen = p.d % 4 != 0 || p.bias != nullptr || p.relu != 0 || p.accumulate != 0;
     const Schedule sc = decide(variant, exact_ok, p.d, p.rows_per_wave, p.n_sel, forced_slice, sh.n_src, sh.avg,
-                               sh.src_line_aligned, gen, sh.short_frac, sh.short_nnz_frac, plan->short_min_frac);
+                               sh.src_line_aligned, gen, sh.short_frac, sh.short_nnz_frac, plan->short_min_frac, sh.n_out);
     const bool short_fb4 = sc.fb4;
     const bool pipe = sc.pipe, scalar128 = sc.scalar128, exact = sc.exact, shortrow = sc.shortrow, lists = sc.lists;
     const int slice = sc.slice;
@@ -802,7 +806,8 @@ int h2gcn_plan_create(int n_hops, int64_t n_rows, int64_t n_cols, const int64_t*
             // ... and, for MIXED operands (the all-hops launch will be list-driven at the usual widths), the segment-class lists
             // of that selection; everything else builds them on the first launch that wants them
             auto mixed = [&](const LaunchShape& sh_) {
-                return plan->variant == 6 || (plan->variant == 0 && sh_.avg >= 16.0 && sh_.short_frac >= plan->short_min_frac);
+                return plan->variant == 6 || (plan->variant == 0 && sh_.short_frac >= plan->short_min_frac &&
+                                              (sh_.avg >= 16.0 || sh_.n_out < 4 * kWavesToFill));
             };
             LaunchShape sh_f = shape_of(plan.get(), all, false);
             if ((st = fill_short(plan.get(), all, false, sh_f)) != H2GCN_OK) return st;
@@ -935,7 +940,7 @@ int h2gcn_plan_schedule(const h2gcn_plan_t* plan, uint32_t hop_mask, int adjoint
     sh.src_line_aligned = (ld_src * 4) % 128 == 0 && (!adjoint || sh.n_sel <= 1 || (d * 4) % 128 == 0);  // aligned base assumed
     const int rs = scratch_slice_cols(plan, sh);
     const Schedule sc = decide(plan->variant, d >= 4, d, plan->rows_per_wave, sh.n_sel, rs > 0 ? rs : plan->slice_cols, sh.n_src, sh.avg,
-                               rs > 0 || sh.src_line_aligned, d % 4 != 0, sh.short_frac, sh.short_nnz_frac, plan->short_min_frac);
+                               rs > 0 || sh.src_line_aligned, d % 4 != 0, sh.short_frac, sh.short_nnz_frac, plan->short_min_frac, sh.n_out);
     const int w = sc.exact ? (sc.slice > 0 ? sc.slice : 128) : d;
     if (slice_cols) *slice_cols = w;
     if (n_slices) *n_slices = sc.exact ? (d + w - 1) / w : 1;
@@ -979,7 +984,7 @@ int h2gcn_plan_segment_classes(const h2gcn_plan_t* plan, uint32_t hop_mask, int 
         sh.src_line_aligned = (ld_src * 4) % 128 == 0 && (!adjoint || sh.n_sel <= 1 || (d * 4) % 128 == 0);
         const int rs = scratch_slice_cols(plan, sh);
         const Schedule sc = decide(plan->variant, d >= 4, d, plan->rows_per_wave, sh.n_sel, rs > 0 ? rs : plan->slice_cols, sh.n_src, sh.avg,
-                                   rs > 0 || sh.src_line_aligned, d % 4 != 0, sh.short_frac, sh.short_nnz_frac, plan->short_min_frac);
+                                   rs > 0 || sh.src_line_aligned, d % 4 != 0, sh.short_frac, sh.short_nnz_frac, plan->short_min_frac, sh.n_out);
         *listed = 0;
         if (sc.lists)
             for (int q = 0; q < sh.n_short_lists; ++q) *listed += sh.short_count[q];

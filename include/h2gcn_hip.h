@@ -69,7 +69,7 @@ typedef struct h2gcn_plan_opts {
                                     waves of one workgroup (LDS-staged partial sums); default 256          */
     int32_t rows_per_wave;       /* consecutive rows a wave walks in the regular path; default 4           */
     int32_t variant;             /* segment walks of the kernel: 0 = default, CSR-adaptive -- long segments
-                                    (>= long_row_threshold): one workgroup each, always; launches whose segments
+                                    (>= long_row_threshold): one workgroup each, always; launches of >= ~50 k rows whose segments
                                     average < 16 nonzeros: in-tile short-row mode (G consecutive short rows per
                                     round, one lane group each) when the slice is 64 or 128 columns, else the wave
                                     walk with index prefetch across segments; MIXED launches (mean >= 16 but at
