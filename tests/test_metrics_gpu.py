@@ -173,6 +173,8 @@ def test_property_sweep_over_shapes_strides_and_weight_patterns():
         p = np.exp(logp)
         want = ws_h[0].astype(np.float64)[:, None] * (p * ys_h[0].astype(np.float64).sum(1, keepdims=True) - ys_h[0])
         got = za.grad.cpu().numpy()
-        assert np.abs(got - want).max() <= 3e-6 * max(1e-3, np.abs(want).max()) + 1e-12
+        # (the entry of the labelled class is w * (p - 1): where p is within a few ulp of 1 -- a confident row, small c -- fp32 can
+        # only hold it to ulp(1) * w, whatever the size of the result; hence the absolute term)
+        assert np.abs(got - want).max() <= 3e-6 * max(1e-3, np.abs(want).max()) + 2.5e-7 * float(ws_h[0].max()) + 1e-12
 
     run()
