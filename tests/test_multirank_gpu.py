@@ -438,6 +438,7 @@ def _run_bench(world, extra, tmp_path, env_extra=None):
         else:
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                 env.pop(k, None)
+        env.setdefault("H2GCN_BENCH_SKIP_DRY", "1")   # the first-contact table is covered by the plain-launch and --dry-exchange tests
         env.update(env_extra or {})
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--no-cpu-baseline",
                                        "--no-probe", "--no-traffic", "--no-hbm-leg"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
