@@ -57,6 +57,15 @@ int main(void) {
     H2(h2gcn_spmm_hops_f32(plan, 0, dx, D, D, dy, H * D, D, NULL));
     H2(h2gcn_spmm_hops_T_f32(plan, 0, dy, H * D, D, D, dg, D, NULL)); /* dX for dY := Y */
     HIP(hipDeviceSynchronize());
+    {   /* CSR-adaptive dispatch, introspection: every segment of this 4-node graph has 1-2 nonzeros -> all "short" */
+        int64_t seg[3 * H], nz[3 * H], listed = 0;
+        H2(h2gcn_plan_segment_classes(plan, 0, 0, D, D, seg, nz, &listed));
+        if (seg[0] != N || seg[1] != 0 || seg[2] != 0 || seg[3] != N || nz[0] != 6 || nz[3] != 4 || listed != 2 * N) {
+            fprintf(stderr, "segment classes: short %lld/%lld medium %lld long %lld, nonzeros %lld/%lld, listed %lld\n", (long long)seg[0],
+                    (long long)seg[3], (long long)seg[1], (long long)seg[2], (long long)nz[0], (long long)nz[3], (long long)listed);
+            return 4;
+        }
+    }
 
     float y[N * H * D], g[N * D];
     HIP(hipMemcpy(y, dy, sizeof y, hipMemcpyDeviceToHost));
