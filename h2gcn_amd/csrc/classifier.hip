@@ -165,7 +165,7 @@ __device__ __forceinline__ f4u apply_mask(f4u v, const MaskKey& mk, int64_t row,
 // ---- small operands (the reference's own datasets: Cora 2 708 rows, citeseer 3 327, syn-products 10 000) -----------------
 // At a few thousand rows the kernels above are one latency chain each -- 7 K-chunks x (fragment fetch, LDS fill, barrier) in
 // a handful of workgroups, plus a weight-packing launch in front: ~18 us per pass on Cora, where a whole training epoch is
-// 0.3 ms (profiles/r04_cora_epoch_kernels.txt: 30 % of it).  Below kSmallRows rows (and C <= 16) three plain VALU kernels
+// 0.3 ms (profiles/r04_cora_epoch_kernels.txt: 30 % of it).  Below ~12 k rows (and C <= 16) three plain VALU kernels
 // serve the forward and dX with the same contract -- same mask generator, same placement of the 1 / keep scale, fp32 FMAs,
 // deterministic -- and the shortest chain each: no packing launch, W^T staged once per workgroup in LDS (12.5 KB on Cora).
 // (dW stays on the matrix-core kernel + its fixed-order reduction: a column-slab walk over all rows in plain code was tried and
@@ -281,7 +281,9 @@ __global__ __launch_bounds__(kThreads) void small_dx_kernel(const float* __restr
     }
 }
 
-int64_t g_small_rows = 32768;   // operands of at most this many rows (and C <= kSmallCP) take the small kernels; 0 = never
+int64_t g_small_rows = 12288;   // operands of at most this many rows (and C <= kSmallCP, K <= kSmallMaxK) take the small kernels; 0 = never
+                                // (measured crossover at K = 448, C = 7: 8 192 rows 16 / 14 us small vs 19 / 19 matrix-core, 16 384 rows 27 / 22 vs
+                                //  20 / 19, 32 768 rows 51 / 47 vs 23 / 22 -- profiles/r04_cora_epoch_kernels.txt)
 size_t small_lds_bytes(int K, int C) { return (size_t)((K + 3) & ~3) * C * 4; }
 bool small_operand(int64_t n_rows, int K, int C) { return n_rows <= g_small_rows && C <= kSmallCP && K <= kSmallMaxK; }
 

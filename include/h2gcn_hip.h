@@ -355,7 +355,7 @@ int h2gcn_hop_normalize_rows(int64_t n_rows, const int64_t* rowptr_dev, const in
  * Arithmetic: v_mfma_f32_16x16x4_f32, i.e. exact fp32 multiply-adds (no reduced precision); the summation order over k
  * (forward), c (dX) and rows (dW) is fixed by the shapes.
  */
-/* Operands of at most this many rows (default 32768) with C <= 16 classes are latency-bound and take three plain kernels instead
+/* Operands of at most this many rows (default 12288) with C <= 16 classes are latency-bound and take three plain kernels instead
  * of the matrix-core ones (same mask, same scale placement, deterministic; Cora: ~18 -> ~5 us per pass).  Sets the bound when
  * rows >= 0 (0 = never; a process-wide tunable, meant for tests and measurements) and returns the previous one. */
 int64_t h2gcn_dropout_dense_small_rows(int64_t rows);

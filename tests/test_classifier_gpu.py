@@ -19,11 +19,11 @@ DEV = "cuda:0"
 @pytest.fixture(autouse=True, params=["matrix-core kernels", "small-operand kernels where they apply"])
 def _kernel_family(request):
     """Every test runs twice: with the latency-optimised small-operand kernels switched off (h2gcn_dropout_dense_small_rows(0):
-    every call on the fp32-MFMA kernels, as in round 3) and with the shipped rule (<= 32768 rows and <= 16 classes: the plain
+    every call on the fp32-MFMA kernels, as in round 3) and with the shipped rule (<= 12288 rows and <= 16 classes: the plain
     kernels).  Same contract, same mask, same tolerance."""
     from h2gcn_amd import _capi
     L = _capi.lib()
-    old = L.h2gcn_dropout_dense_small_rows(0 if request.param.startswith("matrix") else 32768)
+    old = L.h2gcn_dropout_dense_small_rows(0 if request.param.startswith("matrix") else 12288)
     yield request.param
     L.h2gcn_dropout_dense_small_rows(old)
 

@@ -15,6 +15,9 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 2_400_000
 keep = float(sys.argv[4]) if len(sys.argv) > 4 else 0.5
 dev = torch.device("cuda:0")
 lib = _capi.lib()
+import os
+if os.environ.get("H2GCN_CLS_SMALL_ROWS") is not None:      # rows at or below which the small-operand kernels serve the call (0: never)
+    lib.h2gcn_dropout_dense_small_rows(int(os.environ["H2GCN_CLS_SMALL_ROWS"]))
 x = torch.randn((n, k), device=dev)
 w = torch.randn((k, c), device=dev) * 0.05
 b = torch.randn((c,), device=dev)
@@ -53,5 +56,5 @@ def timed(fn, reps=10):
 gb = n * k * 4 / 1e9
 flop = 2.0 * n * k * ((c + 15) // 16 * 16)
 for name, fn in (("forward", fwd), ("backward dX", lambda: bwd(True, False)), ("backward dW (+ reduction)", lambda: bwd(False, True))):
-    t = timed(fn)
+    t = timed(fn, reps=200 if n <= 200_000 else 10)
     print(f"N={n} K={k} C={c} keep={keep}  {name:26s} {t:7.3f} ms   {gb / t * 1e3:6.0f} GB/s of the [N, K] operand   {flop / t / 1e9:6.1f} TFLOP/s fp32 MFMA")
