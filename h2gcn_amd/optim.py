@@ -124,7 +124,10 @@ _PENALTY_WS = {}
 def l2_penalty(params, coefficients) -> torch.Tensor:
     """``sum_k coefficients[k] * sum(params[k] ** 2)`` as a 0-dim tensor WITHOUT a gradient: the value of the keras l2 penalty a
     step reports next to its cross-entropy (reference ``H2GCN.py:363-367``), one kernel launch for all tensors
-    (``h2gcn_l2_penalty_f32``: fp64 inside a tensor, fp32 across tensors).  GPU fp32 contiguous tensors only."""
+    (``h2gcn_l2_penalty_f32``: fp64 inside a tensor, fp32 across tensors).  GPU fp32 contiguous tensors only.  The kernel's scratch
+    (partials + a ticket it re-arms itself) is one persistent buffer per device, allocated on the first call -- before any hipGraph
+    capture, so a replayed step carries no extra fill -- which means calls on ONE device must be stream-ordered with respect to each
+    other (they are: the step closures issue everything on the current stream)."""
     params, coefficients = list(params), [float(c) for c in coefficients]
     n = len(params)
     if n == 0:
