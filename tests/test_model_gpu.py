@@ -457,6 +457,25 @@ def test_entry_point_with_the_l2_penalty_folded_into_adam_follows_the_autograd_r
         assert abs(stats["1"][k] - stats["0"][k]) <= 2e-6 * abs(stats["0"][k]), (k, stats)
 
 
+@pytest.mark.parametrize("name", ["cora", "citeseer"])
+@pytest.mark.parametrize("network", ["M-R-T1-G0-V-T2-G0_1-V-C1_2-S1_0_32-D-MO", "D0.5-M64-R-T1-G1-V-C1-D0.5-MO"])
+def test_replayed_training_equals_eager_on_hop_filter_and_dropout_networks(tmp_path, name, network):
+    """Networks with hop filters (hop-subset launches: their long / segment-class lists are built lazily, during the eager warm-up
+    epochs) and with dropout in front of the sparse embedding (SparseDropout refreshes the feature operand's values every step):
+    40 epochs replayed as hipGraphs end in exactly the statistics of the eager loop -- on Cora (mixed classes: list-driven
+    launches) and citeseer (short throughout, a few thousand rows: list-driven as well)."""
+    from test_entrypoints import _export_fixture
+    from h2gcn_amd import run_experiments
+    data_dir = tmp_path / "data"
+    _export_fixture(load_planetoid_golden(name), data_dir, f"ind.{name}")
+    stats = {}
+    for extra in ([], ["--no_hipgraph"]):
+        args = run_experiments.main(["H2GCN", "planetoid", "--dataset", f"ind.{name}", "--dataset_path", str(data_dir), "--epochs", "40",
+                                     "--random_seed", "3", "--network_setup", network] + extra)
+        stats[bool(extra)] = {k: float(v) for k, v in args.objects["epoch_stats"].items() if k != "monitor"}
+    assert stats[False] == stats[True], stats
+
+
 def test_propagation_reuse_is_off_when_a_dropout_precedes_the_propagation(tmp_path):
     g, data, tensors, setup, model = _setup(tmp_path, "D0.5-M64-R-T1-G-V-T2-G-V-C1-C2-D0.5-MO")
     assert not model.reuse_propagation
