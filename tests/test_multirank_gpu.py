@@ -91,6 +91,20 @@ for halo in (True, False, "auto"):
     layer.check()
     out[str(halo)] = dict(ratio=layer.halo_ratio, used=layer.halo is not None, finite=bool(torch.isfinite(y).all()))
     np.save(f"{os.environ['OUT_DIR']}/y_{halo}_{rank}.npy", y.cpu().numpy())
+    if halo is True:                                # ... and the halo pull is capturable: a replayed hipGraph advances the protocol
+        xs, yg = x[r0:r1].clone(), torch.full_like(y, float("nan"))
+        torch.cuda.synchronize(); dist.barrier()
+        layer.ipc.reset_dependencies()              # a capturing stream must not wait on events of earlier (eager) steps
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            layer(xs, out=yg)
+        for f in layer.full:
+            f.fill_(float("nan"))
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        layer.check()
+        out["replay"] = dict(equal=bool(torch.equal(yg, y)))
     layer.close()
 if rank == 0:
     json.dump(out, open(f"{os.environ['OUT_DIR']}/halo.json", "w"))
@@ -120,7 +134,8 @@ def test_halo_pull_fetches_only_the_named_rows_and_changes_no_bit(tmp_path, grap
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     info = json.loads((tmp_path / "halo.json").read_text())
     print(f"halo pull on {graph}: {info['True']['ratio']:.3f} of the remote rows named / pulled")
-    assert info["True"]["used"] and not info["False"]["used"] and all(v["finite"] for v in info.values()), info
+    assert info["replay"]["equal"], "the replayed halo exchange + SpMM differs from the eager one"
+    assert info["True"]["used"] and not info["False"]["used"] and all(info[k]["finite"] for k in ("True", "False", "auto")), info
     if graph == "banded":
         assert info["auto"]["used"] and info["True"]["ratio"] < 0.25, info
     else:
