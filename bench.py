@@ -409,7 +409,7 @@ def main():
 
     if a.dry_exchange:
         if world < 2:
-            raise SystemExit("--dry-exchange needs N > 1 ranks")
+            raise SystemExit("--dry-exchange needs N > 1 ranks")   # (a usage error, not a measurement: plain message)
         dry_exchange(a, world, rank, device, backend)
         dist.destroy_process_group()
         return
@@ -531,7 +531,7 @@ def main():
                 if rank == 0:   # on record at once: if a later candidate takes the job down, what was measured survives in stderr
                     print(json.dumps({"calibration": key, "ms_per_step": cands[key][0], "n_gpus": world}), file=sys.stderr, flush=True)
         if not cands:
-            raise SystemExit(f"no exchange schedule works: {rejected}")
+            fail_line(a, f"no exchange schedule works on this node: {rejected}", rank)
         best = min(cands, key=lambda k: cands[k][0])
         _, layer, exchange, spec = cands[best]
         chunks = parse_chunks(spec, d)
