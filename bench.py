@@ -710,4 +710,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 -- whatever takes the run down, whoever parses stdout gets ONE line saying so
+        if os.environ.get("RANK", "0") == "0":
+            print(json.dumps({"metric": "aggregated edges/sec (1+2-hop SpMM)", "value": None, "unit": "edges/s",
+                              "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": f"{type(e).__name__}: {e}"[:2000]}), flush=True)
+        raise
