@@ -416,6 +416,10 @@ class PipelinedHopAggregation:
     def _halo_lists(self, plan):
         """Per peer q the ascending LOCAL row ids of q's block that some column id of this rank's hop matrices names (column ids
         live in the row space the exchange lands in: global for equal blocks, padded otherwise)."""
+        key = (self.world, self.rank, self.per, tuple(self.partition.bounds))
+        cache = getattr(plan, "_halo_cache", None)
+        if cache is not None and cache[0] == key:        # (bench.py builds one pipeline per candidate schedule on the same plan)
+            return cache[1]
         cols = torch.unique(torch.cat([c.to(torch.int64) for c in plan.colidx])) if sum(c.numel() for c in plan.colidx) else torch.zeros(0, dtype=torch.int64, device=self.device)
         lists, named, remote = [], 0, 0
         for q in range(self.world):
@@ -428,6 +432,10 @@ class PipelinedHopAggregation:
             lists.append(sel.to(torch.int32).contiguous())
             named += int(sel.numel())
             remote += q1 - q0
+        try:
+            plan._halo_cache = (key, (lists, named, remote))
+        except AttributeError:
+            pass
         return lists, named, remote
 
     def close(self) -> None:
