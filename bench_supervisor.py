@@ -1,0 +1,342 @@
+"""bench_supervisor.py -- keeps `bench.py --gpus N` (N > 1) value-bearing when a rank dies or hangs.
+
+Why it exists: the failure mode of RCCL on first contact with a node is not a Python exception.  A collective that
+never completes is torn down by the ProcessGroupNCCL watchdog -- a C++ abort (SIGABRT) -- and a rank can as well be
+killed by the kernel or sit in a device-side wait for ever.  None of that can be caught inside the rank.  So every
+process the launcher starts (`python -m torch.distributed.run ... bench.py --gpus N`, the driver's form, or the ranks
+`python bench.py --gpus N` launches itself) is only a SUPERVISOR: it holds no GPU context, starts the real rank as a
+child process (`H2GCN_BENCH_WORKER=1`) and watches it.  The supervisors agree on what happened through a key-value
+store (the launcher's own TCPStore on MASTER_ADDR:MASTER_PORT when torch.distributed.run provides one, otherwise one
+hosted by rank 0's supervisor) and walk down a ladder of attempts, each a fresh set of worker processes on a fresh
+rendezvous port:
+
+    attempt 0   what was asked for: first-contact table, calibration over every exchange x chunking, K timed steps
+    attempt 1   conservative: one ncclAllGather per chunk, 2 chunks, no first-contact table, no calibration sweep
+    attempt 2   no RCCL at all: gloo bootstrap + the library's own IPC copy-kernel exchange, 2 chunks
+
+The first attempt whose rank 0 produces a line with a value wins -- that line exists only after the max-over-ranks of
+the K timed steps, so a rank that gets stuck or dies in the tear-down after it no longer matters (the workers are given
+a few seconds, then removed).  Rank 0's supervisor prints that line (stdout carries exactly one line), with what went
+wrong before it under `config.diagnostics.attempts` / `.first_attempt`.  A worker that dies between the timed region and
+its print leaves the measurement on record; the supervisor rebuilds the line from it.  If the ladder runs out, rank 0's
+supervisor prints ONE error line itself, carrying every calibration entry that did complete as `partial`.  A worker is
+given a wall-clock budget; when one rank's worker fails, the others are taken down after a short grace period instead
+of waiting for a collective time-out.
+
+Nothing here touches the measurement: the timed region, the barriers and the max-over-ranks live in the worker.
+"""
+from __future__ import annotations
+
+import datetime
+import json
+import os
+import signal
+import socket
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+METRIC = "aggregated edges/sec (1+2-hop SpMM)"
+USAGE_ERROR = 64   # bench.py's exit code for a command line that cannot run under any schedule (EX_USAGE)
+
+#: the ladder: (name, environment overrides of the workers of that attempt)
+LADDER = (
+    ("as requested", {}),
+    ("conservative: ncclAllGather, 2 chunks, no calibration sweep",
+     {"H2GCN_BENCH_FORCE_EXCHANGE": "allgather", "H2GCN_BENCH_FORCE_CHUNKS": "2", "H2GCN_BENCH_SKIP_DRY": "1"}),
+    ("no RCCL: gloo bootstrap + IPC copy-kernel exchange, 2 chunks",
+     {"H2GCN_BENCH_FORCE_EXCHANGE": "ipc_kernel", "H2GCN_BENCH_FORCE_CHUNKS": "2", "H2GCN_BENCH_SKIP_DRY": "1",
+      "H2GCN_DIST_BACKEND": "gloo"}),
+)
+
+
+def _free_port() -> int:
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _value_line(text: str):
+    """The last stdout line that parses as a bench line (dict with "metric"); None if there is none."""
+    for ln in reversed(text.splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            try:
+                obj = json.loads(ln)
+            except ValueError:
+                continue
+            if isinstance(obj, dict) and "metric" in obj:
+                return obj
+    return None
+
+
+def _progress_entries(path: Path):
+    """What rank 0's worker put on record while it ran (calibration entries, the first-contact table): JSON lines."""
+    out = []
+    try:
+        for ln in path.read_text().splitlines():
+            try:
+                out.append(json.loads(ln))
+            except ValueError:
+                pass
+    except OSError:
+        pass
+    return out
+
+
+class _Store:
+    """The supervisors' key-value store: a client of the launcher's TCPStore when there is one (torch.distributed.run sets
+    TORCHELASTIC_USE_AGENT_STORE=True and serves it on MASTER_PORT), else hosted by rank 0's supervisor on MASTER_PORT
+    (ranks started by hand or by a test).  Keys are prefixed; nothing of the workers' rendezvous ever goes through it."""
+
+    def __init__(self, rank: int, world: int, timeout_s: float):
+        import torch.distributed as dist
+
+        host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ["MASTER_PORT"])
+        td = datetime.timedelta(seconds=timeout_s)
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+        self.hosted = (not agent) and rank == 0
+        base = dist.TCPStore(host, port, None, self.hosted, timeout=td, wait_for_workers=False)
+        self._s = dist.PrefixStore("h2gcn_bench/", base)
+        self._td = datetime.timedelta
+
+    def set(self, key: str, value) -> None:
+        self._s.set(key, str(value))
+
+    def has(self, key: str) -> bool:
+        return bool(self._s.check([key]))
+
+    def get(self, key: str, timeout_s: float):
+        """Value of `key`, or None if it does not appear within `timeout_s`.  Polled (never a blocking store wait): the
+        supervisor must stay responsive to the launcher's SIGTERM."""
+        deadline = time.monotonic() + max(timeout_s, 0.0)
+        while True:
+            try:
+                if self._s.check([key]):
+                    return self._s.get(key).decode()
+            except Exception:  # noqa: BLE001 -- the store is gone (launcher died): same as "never appeared"
+                return None
+            if time.monotonic() >= deadline:
+                return None
+            time.sleep(0.05)
+
+
+class _Worker:
+    """One rank's real bench process, in its own process group (so that everything it started dies with it)."""
+
+    def __init__(self, cmd, env, stdout_path: Path):
+        self.out_path = stdout_path
+        self._out = open(stdout_path, "w")
+        self.p = subprocess.Popen(cmd, env=env, stdout=self._out, start_new_session=True)
+
+    def poll(self):
+        return self.p.poll()
+
+    def kill(self, grace_s: float = 3.0) -> int:
+        """SIGTERM to the worker's process group, SIGKILL after `grace_s`; returns the exit code."""
+        if self.p.poll() is None:
+            for sig, wait in ((signal.SIGTERM, grace_s), (signal.SIGKILL, 10.0)):
+                try:
+                    os.killpg(self.p.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+                try:
+                    self.p.wait(timeout=wait)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+        self._out.close()
+        return self.p.returncode if self.p.returncode is not None else -9
+
+    def peek_stdout(self) -> str:
+        """What the (running) worker has written so far."""
+        try:
+            return self.out_path.read_text()
+        except OSError:
+            return ""
+
+    def stdout(self) -> str:
+        try:
+            self._out.close()
+        except Exception:  # noqa: BLE001
+            pass
+        try:
+            return self.out_path.read_text()
+        except OSError:
+            return ""
+
+
+def _describe_rc(rc) -> str:
+    if rc is None:
+        return "still running"
+    if rc < 0:
+        try:
+            return f"killed by {signal.Signals(-rc).name}"
+        except ValueError:
+            return f"killed by signal {-rc}"
+    return f"exit code {rc}"
+
+
+def supervise(argv, rank: int, world: int) -> int:
+    """Run this rank's worker(s) down the ladder; returns the exit code of the supervisor (0 = a value line was printed by
+    rank 0's supervisor).  `argv` = bench.py's own command line (without the program name)."""
+    budget0 = float(os.environ.get("H2GCN_BENCH_ATTEMPT_BUDGET_S", "900"))       # wall-clock limit of one attempt
+    grace = float(os.environ.get("H2GCN_BENCH_PEER_FAILURE_GRACE_S", "8"))       # how long a worker outlives a failed peer
+    teardown = float(os.environ.get("H2GCN_BENCH_TEARDOWN_GRACE_S", "20"))       # ... and how long it may take to exit after the line
+    n_attempts = max(1, min(len(LADDER), int(os.environ.get("H2GCN_BENCH_MAX_ATTEMPTS", str(len(LADDER))))))
+    store = _Store(rank, world, timeout_s=max(60.0, budget0))
+    tmp = Path(tempfile.mkdtemp(prefix=f"h2gcn_bench_r{rank}_", dir="/tmp"))
+    worker_cmd = os.environ.get("H2GCN_BENCH_WORKER_CMD")     # test hook: a JSON list that replaces `python bench.py <argv>`
+    cmd = json.loads(worker_cmd) if worker_cmd else [sys.executable, str(Path(__file__).resolve().parent / "bench.py")] + list(argv)
+    current = {"w": None}
+
+    def on_signal(signum, _frame):   # the launcher is taking the job down (time limit, ^C): no orphans, and still one line
+        if current["w"] is not None:
+            current["w"].kill(1.0)
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "edges/s", "n_gpus": world,
+                              "error": f"supervisor received {signal.Signals(signum).name}",
+                              "partial": _progress_entries(tmp / "progress.jsonl")}), flush=True)
+        os._exit(128 + signum)
+
+    for s_ in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(s_, on_signal)
+
+    history = []          # rank 0: one entry per failed attempt
+    final = 1
+    for k in range(n_attempts):
+        name, overrides = LADDER[k]
+        # a fresh rendezvous port per attempt: the dead attempt's keys (ncclUniqueId, gloo addresses) must not be found
+        if rank == 0:
+            store.set(f"a{k}/port", _free_port())
+        port = store.get(f"a{k}/port", 120.0)
+        if port is None:
+            history.append({"attempt": k, "schedule": name, "error": "rank 0's supervisor never published the rendezvous port"})
+            break
+        env = dict(os.environ)
+        env.update(overrides)
+        env.update(H2GCN_BENCH_WORKER="1", H2GCN_BENCH_ATTEMPT=str(k), MASTER_PORT=str(port),
+                   H2GCN_BENCH_PROGRESS=str(tmp / "progress.jsonl"), H2GCN_BENCH_SCRATCH=str(tmp))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)     # the workers rendezvous among themselves: rank 0's worker hosts the store
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if k > 0:
+            env["H2GCN_DIST_TIMEOUT_S"] = os.environ.get("H2GCN_BENCH_RETRY_DIST_TIMEOUT_S", "120")
+        w = _Worker(cmd, env, tmp / f"attempt{k}.stdout")
+        current["w"] = w
+        t0 = time.monotonic()
+        why, peer_failed_at, done_at, line = None, None, None, None
+
+        def publish(line_):
+            """rank 0: the measurement is complete the moment its line exists (it is printed after the max-over-ranks of the
+            timed region) -- whatever happens to a rank during tear-down no longer matters."""
+            if history:
+                diag = line_.setdefault("config", {}).setdefault("diagnostics", {})
+                diag["attempts"] = [{"attempt": h["attempt"], "schedule": h["schedule"], "result": h.get("first_failure") or h.get("error")}
+                                    for h in history] + [{"attempt": k, "schedule": name, "result": "ok"}]
+                diag["first_attempt"] = history[0]          # in full: per-rank outcome + every calibration entry it completed
+                if len(history) > 1:
+                    diag["failed_attempts"] = history[1:]
+            store.set(f"a{k}/verdict", "ok")
+            print(json.dumps(line_), flush=True)
+
+        while True:
+            rc = w.poll()
+            if rc is not None:
+                break
+            now = time.monotonic()
+            if done_at is None:
+                if rank == 0:
+                    cand = _value_line(w.peek_stdout())
+                    if cand is not None and cand.get("value") is not None:
+                        line, done_at = cand, now
+                        publish(line)
+                elif store.has(f"a{k}/verdict") and store.get(f"a{k}/verdict", 0.1) == "ok":
+                    done_at = now
+            if done_at is not None:
+                if now - done_at > teardown:      # a rank stuck in its final barrier / destroy_process_group: the result stands
+                    rc = w.kill()
+                    break
+                time.sleep(0.1)
+                continue
+            if now - t0 > budget0:
+                why = f"no result within the attempt's budget of {budget0:.0f} s"
+                store.set(f"a{k}/failed", f"rank {rank}: {why}")
+                rc = w.kill()
+                break
+            if peer_failed_at is None and store.has(f"a{k}/failed"):
+                peer_failed_at = now
+            if peer_failed_at is not None and now - peer_failed_at > grace:
+                why = "taken down after a peer failed: " + (store.get(f"a{k}/failed", 1.0) or "?")
+                rc = w.kill()
+                break
+            time.sleep(0.1)
+        current["w"] = None
+        if done_at is not None:            # success was declared while the worker was still tearing down
+            final = 0
+            break
+        if rc != 0 and why is None:
+            why = _describe_rc(rc)
+            store.set(f"a{k}/failed", f"rank {rank}: {why}")
+        store.set(f"a{k}/rc{rank}", rc)
+        if rank != 0:
+            verdict = store.get(f"a{k}/verdict", budget0 + 120.0)
+            if verdict == "ok":
+                final = 0
+                break
+            if verdict is None or verdict == "fail":
+                break
+            continue
+        # rank 0: its worker is gone.  A value line = success (see publish); otherwise collect the exit codes for the record
+        line = _value_line(w.stdout())
+        if line is not None and line.get("value") is not None:
+            publish(line)
+            final = 0
+            break
+        measured = [e["measured"] for e in _progress_entries(tmp / "progress.jsonl") if e.get("attempt", k) == k and "measured" in e]
+        if measured:
+            # the K timed steps completed on every rank (the entry is written after the max-over-ranks) and the worker died in
+            # what follows (diagnostics, CPU legs): the measurement stands, the line is rebuilt from the record
+            line = dict(measured[-1])
+            line["roofline"] = None
+            line["cpu_baseline"] = None
+            line.setdefault("config", {})["diagnostics"] = {
+                "rebuilt_by_supervisor": f"rank 0's worker ended ({_describe_rc(rc)}) after the timed region and before printing its line; "
+                                         "value / ms_per_step are the worker's own max-over-ranks timing of the K steps",
+                "calibration": [e for e in _progress_entries(tmp / "progress.jsonl") if e.get("attempt", k) == k and "calibration" in e]}
+            publish(line)
+            final = 0
+            break
+        rcs = {0: rc}
+        for q in range(1, world):
+            v = store.get(f"a{k}/rc{q}", grace + 30.0)     # the others follow within the peer-failure grace period
+            rcs[q] = None if v is None else int(v)
+        entry = {"attempt": k, "schedule": name,
+                 "ranks": {str(q): ("ok" if v == 0 else _describe_rc(v)) for q, v in rcs.items()},
+                 "first_failure": store.get(f"a{k}/failed", 0.1),
+                 "calibration": [e for e in _progress_entries(tmp / "progress.jsonl") if e.get("attempt", k) == k]}
+        if line is not None and line.get("error"):
+            entry["error_line"] = line["error"]
+        history.append(entry)
+        print(json.dumps({"supervisor": f"attempt {k} ({name}) failed", "ranks": entry["ranks"], "first_failure": entry["first_failure"]}),
+              file=sys.stderr, flush=True)
+        # exit code 64 on every rank = the command line itself is wrong (bench.py's usage errors): no schedule will fix that
+        last = k == n_attempts - 1 or all(v == USAGE_ERROR for v in rcs.values())
+        store.set(f"a{k}/verdict", "fail" if last else "retry")
+        if last:
+            break
+    if rank == 0 and final != 0:
+        partial = [e for h in history for e in h.get("calibration", [])]
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "edges/s", "n_gpus": world,
+                          "error": f"every attempt failed ({len(history)} of {n_attempts}): "
+                                   + "; ".join(f"[{h['attempt']}] {h.get('error_line') or h.get('first_failure') or h.get('error') or h.get('ranks')}"
+                                               for h in history),
+                          "attempts": history, "partial": partial}), flush=True)
+    # a store hosted by rank 0's supervisor must outlive the other supervisors' last look at it
+    store.set(f"bye{rank}", 1)
+    if store.hosted:
+        for q in range(1, world):
+            store.get(f"bye{q}", 30.0)
+    return final

@@ -43,6 +43,78 @@ def init_rccl_process_group(device: torch.device, timeout_s: Optional[float] = N
         dist.init_process_group("nccl", device_id=device, **kw)
 
 
+def enable_rccl_debug_log(directory: str) -> None:
+    """Have RCCL write what it decides at communicator set-up (topology graph, channels, transports) and per collective
+    (algorithm / protocol) into one FILE per process under ``directory`` -- never to stdout/stderr.  Must run before the
+    process group is created.  Ring-vs-direct is what decides the 8-GPU outcome of the per-layer all-gather
+    (SURVEY.md §7), so a multi-rank run keeps this next to its number; existing NCCL_DEBUG* settings are respected."""
+    os.makedirs(directory, exist_ok=True)
+    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING")
+    os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(directory, "rccl.%h.%p"))
+
+
+def summarize_rccl_log(directory: Optional[str] = None, pid: Optional[int] = None, max_lines: int = 10):
+    """At most ``max_lines`` strings saying what RCCL chose in this process: version, communicator size, channel count,
+    transports per connection (P2P/IPC over xGMI vs SHM vs NET), rings/trees, and the distinct algorithm/protocol picks.
+    Reads the file :func:`enable_rccl_debug_log` named (``$NCCL_DEBUG_FILE`` with %h/%p expanded); an empty list when
+    there is no such file."""
+    import glob
+    import re
+    import socket
+
+    pattern = os.environ.get("NCCL_DEBUG_FILE", "") if directory is None else os.path.join(directory, "rccl.%h.%p")
+    if not pattern:
+        return []
+    pid = os.getpid() if pid is None else pid
+    path = pattern.replace("%h", socket.gethostname()).replace("%p", str(pid))
+    files = [path] if os.path.exists(path) else sorted(glob.glob(pattern.replace("%h", "*").replace("%p", str(pid))))
+    if not files:
+        return []
+    try:
+        text = open(files[0], errors="replace").read()
+    except OSError:
+        return []
+    body = [re.sub(r"^.*?NCCL (INFO|WARN) ", lambda m: "WARN " if m.group(1) == "WARN" else "", ln).strip() for ln in text.splitlines()]
+    out, seen = [], set()
+
+    def add(s):
+        s = s[:240]
+        if s and s not in seen and len(out) < max_lines:
+            seen.add(s)
+            out.append(s)
+
+    for pat in (r"(RCCL|NCCL) version", r"nranks \d+.*(Init COMPLETE|init)", r"\d+ coll channels"):
+        for ln in body:
+            if re.search(pat, ln):
+                add(ln)
+                break
+    chans = {int(m.group(1)) for ln in body for m in [re.match(r"Channel \d+/(\d+)\s*:", ln)] if m}
+    if chans:
+        add(f"ring channels: {max(chans)}")
+    via = {}
+    for ln in body:
+        m = re.search(r"\bvia (\S+)", ln)
+        if m:
+            via[m.group(1)] = via.get(m.group(1), 0) + 1
+    if via:
+        add("connections by transport: " + ", ".join(f"{k} x{v}" for k, v in sorted(via.items())))
+    for ln in body:
+        if ln.startswith("WARN"):
+            add(ln)
+    for ln in body:   # e.g. "AllGather: 39321600 Bytes -> Algo 1 proto 2 time ..." (TUNING): the distinct picks
+        m = re.search(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)", ln)
+        if m:
+            add(f"{m.group(1)} {m.group(2)} B -> algo {m.group(3)} (0 tree, 1 ring, ...) proto {m.group(4)} (0 LL, 1 LL128, 2 simple)")
+    for ln in body:
+        if re.search(r"^(Ring|Trees?) ", ln) or "Connected all" in ln:
+            add(ln)
+    if not out:   # a log that matches none of the patterns: its first lines are still better than nothing
+        for ln in body[:max_lines]:
+            add(ln)
+    return out
+
+
 def block_bounds(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
     """[r0, r1) of ``rank``'s row block: equal blocks of ceil(n/P) rows."""
     if world_size < 1 or not (0 <= rank < world_size):

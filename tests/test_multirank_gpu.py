@@ -582,6 +582,69 @@ def test_bench_plain_launch_spawns_its_own_ranks(tmp_path):
     _keep("bench_plain_launch_arxiv_n2.json", out)
 
 
+def _run_supervised(world, extra, env_extra, timeout=1500):
+    """`world` launcher-style ranks of bench.py sharing the box's GPU (each one a bench_supervisor with the real worker as its
+    child); returns (stdout lines of rank 0, stderr of rank 0, exit codes)."""
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = {k: v for k, v in os.environ.items() if k != "H2GCN_BENCH_WORKER"}
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1", H2GCN_BENCH_SKIP_DRY="1",
+                   H2GCN_BENCH_EXCHANGES="allgather,ipc_kernel", H2GCN_BENCH_PEER_FAILURE_GRACE_S="2")
+        env.update(env_extra)
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--shape", "arxiv", "--steps", "2",
+                                       "--warmup", "1", "--no-cpu-baseline", "--no-probe", "--no-traffic", "--no-hbm-leg", "--no-adjoint"] + extra,
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    for o in outs[1:]:
+        assert o[0].strip() == "", o[0]
+    return [ln for ln in outs[0][0].splitlines() if ln.strip()], outs[0][1], [p.returncode for p in procs]
+
+
+def test_bench_survives_a_rank_that_aborts(tmp_path):
+    """VERDICT r4 item 1.  Rank 1 dies with SIGABRT (os.abort(): what the ProcessGroupNCCL watchdog does to a rank whose
+    collective timed out -- not a Python exception) right after the first candidate has been timed.  stdout still carries
+    exactly one line, with a value (measured by the conservative relaunch: ncclAllGather-style exchange, 2 chunks, fresh
+    rendezvous), the bits of the single-GPU result, and the first attempt's record under diagnostics.first_attempt."""
+    lines, err, rcs = _run_supervised(2, [], {"H2GCN_BENCH_ABORT_RANK": "1"})
+    assert len(lines) == 1 and rcs == [0, 0], (lines, err[-3000:])
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["n_gpus"] == 2 and out["config"]["checksum_matches_n1"] is True
+    diag = out["config"]["diagnostics"]
+    assert diag["exchange"] == "allgather" and list(diag["calibration_ms_per_step"]) == ["allgather/2"]
+    first = diag["first_attempt"]
+    assert first["ranks"]["1"] == "killed by SIGABRT" and first["attempt"] == 0
+    cal = [e for e in first["calibration"] if "ms_per_step" in e]
+    assert len(cal) == 1 and cal[0]["calibration"] == "allgather/2" and cal[0]["ms_per_step"] > 0   # safest candidate first
+    assert diag["attempts"][-1] == {"attempt": 1, "schedule": diag["attempts"][-1]["schedule"], "result": "ok"}
+    _keep("bench_shared_gpu_rank_abort_n2.json", out)
+
+
+def test_bench_rank_aborting_in_every_attempt_is_one_error_line(tmp_path):
+    """The same injection honoured on every rung of the ladder: one error line (value null) that still carries every
+    calibration entry that completed, as `partial`."""
+    lines, err, rcs = _run_supervised(2, [], {"H2GCN_BENCH_ABORT_RANK": "1", "H2GCN_BENCH_FAIL_ATTEMPTS": "0,1,2"})
+    assert len(lines) == 1 and rcs[0] != 0, (lines, err[-3000:])
+    out = json.loads(lines[0])
+    assert out["value"] is None and "every attempt failed (3 of 3)" in out["error"] and len(out["attempts"]) == 3
+    timed = [e for e in out["partial"] if "ms_per_step" in e]
+    assert sorted(e["attempt"] for e in timed) == [0, 1, 2] and all(e["ms_per_step"] > 0 for e in timed)
+    assert {e["calibration"] for e in timed} == {"allgather/2", "ipc_kernel/2"}      # rung 2 runs the library's own exchange
+
+
+def test_bench_survives_a_rank_that_hangs_inside_exchange_only(tmp_path):
+    """A rank that stops responding (never returns from the diagnostics' exchange_only stage) instead of dying: its peers
+    block in the collective; the attempt's wall-clock budget takes all of them down and the relaunch delivers the line."""
+    lines, err, rcs = _run_supervised(2, ["--chunks", "2"], {"H2GCN_BENCH_HANG_RANK": "1", "H2GCN_BENCH_FAIL_STAGE": "exchange_only",
+                                                             "H2GCN_BENCH_ATTEMPT_BUDGET_S": "100", "H2GCN_DIST_TIMEOUT_S": "900"})
+    assert len(lines) == 1 and rcs == [0, 0], (lines, err[-3000:])
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["config"]["checksum_matches_n1"] is True
+    first = out["config"]["diagnostics"]["first_attempt"]
+    assert "budget" in first["first_failure"] and len([e for e in first["calibration"] if "ms_per_step" in e]) >= 2
+
+
 def test_bench_more_ranks_than_gpus_is_one_error_line():
     """`--gpus N` beyond the visible devices: ONE JSON line with "error" and a non-zero exit code, no traceback."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "H2GCN_SHARE_GPU")}
