@@ -100,7 +100,9 @@ def cpu_baseline(plan_csr, x_full, d, target_seconds=12.0):
     # the same C loop with the output rows spread over all host cores (OpenMP; identical bits) -- an upper bound on what
     # a parallelised build of the reference's CPU kernel could do on this host
     try:
-        threads = len(os.sched_getaffinity(0))
+        # threads the OpenMP runtime will really use: OMP_NUM_THREADS when set (torch.distributed.run exports 1 per rank;
+        # bench_supervisor widens that for its workers), else every core this process may run on
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or len(os.sched_getaffinity(0))
         og.gcn_layer_c(parts, x_cpu, threads=True)  # warm-up (thread pool)
         t = time.perf_counter()
         og.gcn_layer_c(parts, x_cpu, threads=True)
@@ -464,7 +466,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("H2GCN_DIST_BACKEND", "nccl")  # "gloo" only for the shared-GPU test mode
-        timeout_s = float(os.environ.get("H2GCN_DIST_TIMEOUT_S", "180"))  # a failed rank must not hang its peers forever
+        timeout_s = float(os.environ.get("H2GCN_DIST_TIMEOUT_S", "120"))  # a failed rank must not hang its peers forever
         if backend == "nccl":
             from h2gcn_amd.partition import enable_rccl_debug_log, init_rccl_process_group
             # a collective that exceeds timeout_s: the watchdog tears the process down (SIGABRT) -- the supervisor's ladder

@@ -183,7 +183,11 @@ def _describe_rc(rc) -> str:
 def supervise(argv, rank: int, world: int) -> int:
     """Run this rank's worker(s) down the ladder; returns the exit code of the supervisor (0 = a value line was printed by
     rank 0's supervisor).  `argv` = bench.py's own command line (without the program name)."""
-    budget0 = float(os.environ.get("H2GCN_BENCH_ATTEMPT_BUDGET_S", "900"))       # wall-clock limit of one attempt
+    # wall-clock limit of the first attempt (a healthy 8-rank run takes one to two minutes; a collective that never completes is
+    # torn down by the watchdog after H2GCN_DIST_TIMEOUT_S = 120 s: the budget is the backstop behind that) and of a retry
+    budget_first = float(os.environ.get("H2GCN_BENCH_ATTEMPT_BUDGET_S", "420"))
+    budget_retry = float(os.environ.get("H2GCN_BENCH_RETRY_BUDGET_S", os.environ.get("H2GCN_BENCH_ATTEMPT_BUDGET_S", "240")))
+    budget0 = budget_first
     grace = float(os.environ.get("H2GCN_BENCH_PEER_FAILURE_GRACE_S", "8"))       # how long a worker outlives a failed peer
     teardown = float(os.environ.get("H2GCN_BENCH_TEARDOWN_GRACE_S", "20"))       # ... and how long it may take to exit after the line
     n_attempts = max(1, min(len(LADDER), int(os.environ.get("H2GCN_BENCH_MAX_ATTEMPTS", str(len(LADDER))))))
@@ -209,6 +213,7 @@ def supervise(argv, rank: int, world: int) -> int:
     final = 1
     for k in range(n_attempts):
         name, overrides = LADDER[k]
+        budget0 = budget_first if k == 0 else budget_retry
         # a fresh rendezvous port per attempt: the dead attempt's keys (ncclUniqueId, gloo addresses) must not be found
         if rank == 0:
             store.set(f"a{k}/port", _free_port())
@@ -222,8 +227,14 @@ def supervise(argv, rank: int, world: int) -> int:
                    H2GCN_BENCH_PROGRESS=str(tmp / "progress.jsonl"), H2GCN_BENCH_SCRATCH=str(tmp))
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)     # the workers rendezvous among themselves: rank 0's worker hosts the store
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if env.get("OMP_NUM_THREADS") == "1" and "H2GCN_BENCH_OMP_NUM_THREADS" not in env:
+            # torch.distributed.run exports OMP_NUM_THREADS=1 per rank; the reported CPU baselines (rank 0, after the timed region)
+            # are labelled with the threads they use, so give every worker its share of the host instead
+            env["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // world))
+        elif "H2GCN_BENCH_OMP_NUM_THREADS" in env:
+            env["OMP_NUM_THREADS"] = env["H2GCN_BENCH_OMP_NUM_THREADS"]
         if k > 0:
-            env["H2GCN_DIST_TIMEOUT_S"] = os.environ.get("H2GCN_BENCH_RETRY_DIST_TIMEOUT_S", "120")
+            env["H2GCN_DIST_TIMEOUT_S"] = os.environ.get("H2GCN_BENCH_RETRY_DIST_TIMEOUT_S", "90")
         w = _Worker(cmd, env, tmp / f"attempt{k}.stdout")
         current["w"] = w
         t0 = time.monotonic()
@@ -313,9 +324,12 @@ def supervise(argv, rank: int, world: int) -> int:
         for q in range(1, world):
             v = store.get(f"a{k}/rc{q}", grace + 30.0)     # the others follow within the peer-failure grace period
             rcs[q] = None if v is None else int(v)
+        # what the store saw first is often a SYMPTOM (a peer's connection reset); a rank that died of a signal nobody here sent
+        # (SIGABRT: the watchdog; SIGSEGV; the OOM killer's SIGKILL arrives as -9 too, but so do our own kills) is the cause
+        died = [f"rank {q}: {_describe_rc(v)}" for q, v in rcs.items() if v is not None and v < 0 and -v not in (signal.SIGTERM, signal.SIGKILL)]
         entry = {"attempt": k, "schedule": name,
                  "ranks": {str(q): ("ok" if v == 0 else _describe_rc(v)) for q, v in rcs.items()},
-                 "first_failure": store.get(f"a{k}/failed", 0.1),
+                 "first_failure": died[0] if died else store.get(f"a{k}/failed", 0.1),
                  "calibration": [e for e in _progress_entries(tmp / "progress.jsonl") if e.get("attempt", k) == k]}
         if line is not None and line.get("error"):
             entry["error_line"] = line["error"]

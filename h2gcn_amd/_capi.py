@@ -266,12 +266,19 @@ def lib() -> C.CDLL:
     L.h2gcn_xchg_destroy.restype = None
     L.h2gcn_xchg_destroy.argtypes = [C.c_void_p]
     got = L.h2gcn_abi_version()
-    # (an explicitly named older build -- H2GCN_HIP_LIBRARY, the A/B tools -- may lack entry points added later: ABI 4 only
-    # ADDED h2gcn_plan_segment_classes)
+    # An explicitly named ABI-3 build (H2GCN_HIP_LIBRARY: the interleaved A/B tools time an older kernel) is accepted.  It lacks
+    # what later rounds ADDED -- h2gcn_plan_segment_classes, h2gcn_adam_keras_l2_f32 / h2gcn_l2_penalty_*,
+    # h2gcn_xchg_allgather_pull_rows -- and every caller of those asks `has()` first: the front end then keeps the l2 penalty in
+    # the autograd graph, pulls whole shards, and HopPlan.segment_classes raises a message instead of an AttributeError.
     if got != ABI_VERSION and not (os.environ.get("H2GCN_HIP_LIBRARY") and got == 3):
         raise RuntimeError(f"{path}: ABI version {got}, this front end expects {ABI_VERSION}")
     _LIB = L
     return L
+
+
+def has(symbol: str) -> bool:
+    """Does the loaded library export ``symbol``?  (False only for an older build named through H2GCN_HIP_LIBRARY.)"""
+    return hasattr(lib(), symbol)
 
 
 def check(status: int) -> None:

@@ -181,6 +181,26 @@ void collect_segment_lengths(const std::vector<int64_t>& rowptr, int64_t n_rows,
 // long segment (those belong to the long list).  The COUNTS (what the schedule is decided from) are computed on first use;
 // the device lists only when `build` is set, i.e. once a launch really is list-driven -- a products-sized operand whose
 // launches stay on the tile walk never pays the 4 bytes per row and class.
+// Set by the launch entry points for the duration of a call: the launch stream is being captured into a hipGraph.  The device
+// lists of a hop selection are built by its FIRST launch (an allocation and a synchronous upload) -- neither may happen inside
+// a capture, and a fallback to another walk would silently bake the slower schedule into the graph: such a launch is refused
+// with a message that says what to do (run it once eagerly first; all-hops selections are prepared at plan creation).
+thread_local bool t_stream_capturing = false;
+
+struct CaptureScope {
+    explicit CaptureScope(hipStream_t stream) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        t_stream_capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        if (!t_stream_capturing) (void)hipGetLastError();
+    }
+    ~CaptureScope() { t_stream_capturing = false; }
+};
+
+int refuse_build_while_capturing(const char* what) {
+    return fail(H2GCN_ERR_INVALID_ARGUMENT, "the stream is being captured and this is the first launch of this hop selection: its %s "
+                "has to be built first (device allocation + upload).  Run the same launch once outside the capture (a warm-up step)", what);
+}
+
 int get_class_lists(const h2gcn_plan* plan, bool adjoint, int k, uint32_t mask, bool build, const ClassLists** out) {
     *out = nullptr;
     const std::vector<HopOperand>& ops = adjoint ? plan->adj : plan->fwd;
@@ -220,6 +240,7 @@ int get_class_lists(const h2gcn_plan* plan, bool adjoint, int k, uint32_t mask, 
     }
     ClassLists& cl = it->second;
     if (build && !cl.built) {
+        if (t_stream_capturing) return refuse_build_while_capturing("per-class row lists");
         std::vector<int32_t> h_short, h_med;
         h_short.reserve((size_t)cl.n_short);
         h_med.reserve((size_t)cl.n_med);
@@ -296,6 +317,7 @@ int get_long_list(const h2gcn_plan* plan, bool adjoint, uint32_t mask, const int
         }
         LongList fresh;  // inserted into the cache only once it is complete
         fresh.n = (int)host.size();
+        if (fresh.n > 0 && t_stream_capturing) return refuse_build_while_capturing("long-segment list");
         if (fresh.n > 0) {
             H2GCN_HIP_TRY(hipMalloc(&fresh.dev.p, host.size() * sizeof(int64_t)));
             H2GCN_HIP_TRY(hipMemcpy(fresh.dev.p, host.data(), host.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -1043,6 +1065,7 @@ int h2gcn_spmm_hops_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const 
         if (!X && plan->n_cols > 0) return fail(H2GCN_ERR_INVALID_ARGUMENT, "X is NULL");
         if (ldx < d) return fail(H2GCN_ERR_INVALID_ARGUMENT, "ldx = %lld < d = %d", (long long)ldx, d);
         if (ldy_hop < 0 || ldy_row < 0) return fail(H2GCN_ERR_INVALID_ARGUMENT, "negative output stride");
+        CaptureScope capture_scope((hipStream_t)stream_v);
         LaunchParams p;
         memset(&p, 0, sizeof(p));
         LaunchShape sh = shape_of(plan, mask, false);
@@ -1119,6 +1142,7 @@ int h2gcn_spmm_hops_T_opts_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, cons
         if (!dY && plan->n_rows > 0) return fail(H2GCN_ERR_INVALID_ARGUMENT, "dY is NULL");
         if (ldx < d) return fail(H2GCN_ERR_INVALID_ARGUMENT, "ldx = %lld < d = %d", (long long)ldx, d);
         if (ldg_row < d || ldg_hop < 0) return fail(H2GCN_ERR_INVALID_ARGUMENT, "bad gradient strides");
+        CaptureScope capture_scope((hipStream_t)stream_v);
         LaunchParams p;
         memset(&p, 0, sizeof(p));
         LaunchShape sh = shape_of(plan, mask, true);

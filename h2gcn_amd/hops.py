@@ -161,6 +161,8 @@ class HopPlan:
         launch takes from the binned short list (``listed``; 0 = the wave walk serves the short class too, -1 = in-tile
         short-row mode: rounds of consecutive short rows are grouped on the fly)."""
         L = _capi.lib()
+        if not _capi.has("h2gcn_plan_segment_classes"):
+            raise RuntimeError(f"{_capi.library_path()} predates h2gcn_plan_segment_classes (ABI 4)")
         h_sel = self.n_selected(hops)
         seg, nnz, listed = (C.c_int64 * (3 * h_sel))(), (C.c_int64 * (3 * h_sel))(), C.c_int64()
         ld = int(ld_src) if ld_src is not None else (h_sel * d if adjoint else d)

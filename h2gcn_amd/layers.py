@@ -388,8 +388,6 @@ class DropoutDense(torch.nn.Module):
     forward, keyed by ``(seed, step)``; ``step`` lives in a device counter bumped by a stream-ordered op, so a replayed
     hipGraph draws a fresh mask every epoch."""
 
-    _instances = 0   # per-process construction counter: the default salt of a layer's mask stream
-
     def __init__(self, input_dim: int, units: int, use_bias: bool, drop_prob: float, seed: Optional[int] = None):
         super().__init__()
         self.kernel = torch.nn.Parameter(torch.empty(input_dim, units))
@@ -398,11 +396,12 @@ class DropoutDense(torch.nn.Module):
         self.drop_prob = float(drop_prob)
         if seed is None:
             # the mask is a pure function of (seed, step, row, column group) and every layer's step counter advances in
-            # lock step: without a per-layer salt two DropoutDense layers of one model would draw IDENTICAL masks.  (Models
-            # built in the same order under the same torch seed get the same streams; H2GCN passes seed = initial_seed + layer
-            # index explicitly.)
-            seed = torch.initial_seed() + 0x632BE59BD9B4E019 * (DropoutDense._instances + 1)
-            DropoutDense._instances += 1
+            # lock step: without a per-layer salt two DropoutDense layers of one model would draw IDENTICAL masks.  The
+            # salt is drawn from torch's default generator right after the kernel's initialisation, like one more weight:
+            # a pure function of torch.manual_seed and the construction order of THIS model -- never of what else the
+            # process built before (repeated runs of run_experiments, one test after another).  H2GCN passes
+            # seed = initial_seed + layer index explicitly.
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         self.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             # row-partitioned runs: the kernels index the mask by LOCAL row, so every rank gets its own stream (otherwise row i

@@ -132,8 +132,9 @@ def initialize_model(args, layer_setups, optimizer, lr, l2_regularize_weight, ea
     # reduction, a multiply and an add per kernel per loss plus the backward of all that (on Cora ~25 of an epoch's 65 launches,
     # profiles/r04_cora_epoch_kernels.txt).  Other optimizers / CPU runs keep the penalty inside the autograd graph.
     from ..optim import KerasAdam
+    from .. import _capi
     fused_l2 = (isinstance(optimizer, KerasAdam) and model.l2 > 0 and bool(model.regularized) and device.type == "cuda"
-                and os.environ.get("H2GCN_FUSED_L2", "1") != "0")
+                and os.environ.get("H2GCN_FUSED_L2", "1") != "0" and _capi.has("h2gcn_adam_keras_l2_f32"))
     if fused_l2:
         optimizer.set_l2([layer.kernel for layer in model.regularized], model.l2)
     model.fused_l2 = fused_l2
@@ -723,9 +724,22 @@ class H2GCN(torch.nn.Module):
         accumulate into that gradient tensor in place."""
         if (end - 1) in self.tags:
             return False
-        while end < len(self.layer_objs) and isinstance(self.layer_objs[end], torch.nn.Identity) and end not in self.tags:
-            end += 1       # (the placeholder a `D` leaves when the following dense layer applies the dropout itself)
-        return end < len(self.layer_objs) and isinstance(self.layer_objs[end], (L.DropoutDense, Dense, torch.nn.Dropout))
+
+        def passes_through(layer) -> bool:
+            # layers that hand their INPUT on as their output, with no autograd node of their own: the gradient that reaches the
+            # buffer is then whatever the layer after them supplies.  nn.Identity (the placeholder a `D` leaves when the following
+            # dense layer applies the dropout itself); nn.Dropout in eval mode or with rate 0 (F.dropout returns its input)
+            if isinstance(layer, torch.nn.Identity):
+                return True
+            return isinstance(layer, torch.nn.Dropout) and (not layer.training or layer.p == 0)
+
+        while end < len(self.layer_objs) and passes_through(self.layer_objs[end]) and end not in self.tags:
+            end += 1
+        if end >= len(self.layer_objs):
+            return False           # the buffer is the model's output: its gradient belongs to the caller
+        nxt = self.layer_objs[end]
+        # an ACTIVE nn.Dropout multiplies by its mask in backward: a fresh tensor.  DropoutDense / Dense: a fresh GEMM output.
+        return isinstance(nxt, (L.DropoutDense, Dense)) or (isinstance(nxt, torch.nn.Dropout) and nxt.training and nxt.p > 0)
 
     def restore_sparse_inputs(self) -> None:
         """Undo what ``SparseDropout`` did to the shared sparse feature operand (after the backward pass)."""

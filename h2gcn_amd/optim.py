@@ -35,6 +35,11 @@ class KerasAdam(torch.optim.Optimizer):
             raise ValueError(f"KerasAdam.set_l2: coefficient {coefficient}")
         for p in params:
             self._l2[id(p)] = float(coefficient)
+            if p.is_cuda and _capi.has("h2gcn_l2_penalty_workspace_bytes"):
+                # the step closures report the penalty's VALUE through l2_penalty(): its scratch must exist (and be zero) BEFORE
+                # any hipGraph capture -- a buffer first allocated inside a capture lives in the graph's private pool, its zero-fill
+                # recorded but not yet executed
+                _penalty_workspace(p.device)
 
     def _state(self, p):
         st = self.state[p]
@@ -51,7 +56,9 @@ class KerasAdam(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             lr, b1, b2, eps = group["lr"], group["beta_1"], group["beta_2"], group["epsilon"]
-            ps = [p for p in group["params"] if p.grad is not None]
+            # a kernel registered with set_l2 whose data gradient is absent (it did not take part in this loss) still owes the
+            # penalty's 2*l2*w -- what autograd would have produced had the penalty been part of the loss: step it on zeros
+            ps = [p for p in group["params"] if p.grad is not None or self._l2.get(id(p), 0.0)]
             if not ps:
                 continue
             # one step counter per group, on the device of its first parameter (host copy for the CPU formula)
@@ -61,7 +68,8 @@ class KerasAdam(torch.optim.Optimizer):
             fast = [p for p in ps if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.device == group["step_dev"].device]
             slow = [p for p in ps if not any(p is q for q in fast)]
             if fast:
-                grads = [p.grad if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else p.grad.to(torch.float32).contiguous() for p in fast]
+                grads = [torch.zeros_like(p, memory_format=torch.contiguous_format) if p.grad is None else
+                         (p.grad if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else p.grad.to(torch.float32).contiguous()) for p in fast]
                 states = [self._state(p) for p in fast]
                 n = len(fast)
                 arr = C.c_void_p * n
@@ -87,7 +95,7 @@ class KerasAdam(torch.optim.Optimizer):
                 st = self._state(p)
                 one, tb1, tb2 = (torch.tensor(x, dtype=torch.float32) for x in (1.0, b1, b2))   # fp32 like the kernel
                 alpha = (torch.tensor(lr, dtype=torch.float32) * torch.sqrt(one - tb2 ** t) / (one - tb1 ** t)).item()
-                g = p.grad
+                g = p.grad if p.grad is not None else torch.zeros_like(p)
                 if self._l2.get(id(p), 0.0):
                     g = g + p * (2.0 * self._l2[id(p)])
                 st["m"].add_((g - st["m"]) * (one - tb1).item())
@@ -121,13 +129,33 @@ class KerasAdam(torch.optim.Optimizer):
 _PENALTY_WS = {}
 
 
+def _penalty_workspace(dev) -> torch.Tensor:
+    """Scratch of ``h2gcn_l2_penalty_f32`` (partials + a ticket the kernel re-arms itself): ONE zero-initialised buffer per device
+    (a captured step and the eager steps around it must use the same one, and a capture runs on a stream of its own -- so not per
+    stream: calls on one device have to be stream-ordered with respect to each other, which the step closures are).  It must come
+    into being OUTSIDE a hipGraph capture -- ``KerasAdam.set_l2`` sees to that: created inside one it would live in the graph's
+    private pool with its zero-fill only recorded, and an eager call before the first replay would read a garbage ticket and
+    never write its result."""
+    dev = torch.device(dev)
+    ws = _PENALTY_WS.get(dev)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("l2_penalty: first use on this device inside a hipGraph capture -- call it (or KerasAdam.set_l2) "
+                               "once eagerly first: its workspace cannot be created inside a capture")
+        with torch.cuda.device(dev):
+            ws = torch.zeros(int(_capi.lib().h2gcn_l2_penalty_workspace_bytes()) // 8 + 1, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)       # the fill has executed before anything, on any stream, can use the buffer
+        _PENALTY_WS[dev] = ws
+    return ws
+
+
 def l2_penalty(params, coefficients) -> torch.Tensor:
     """``sum_k coefficients[k] * sum(params[k] ** 2)`` as a 0-dim tensor WITHOUT a gradient: the value of the keras l2 penalty a
     step reports next to its cross-entropy (reference ``H2GCN.py:363-367``), one kernel launch for all tensors
     (``h2gcn_l2_penalty_f32``: fp64 inside a tensor, fp32 across tensors).  GPU fp32 contiguous tensors only.  The kernel's scratch
-    (partials + a ticket it re-arms itself) is one persistent buffer per device, allocated on the first call -- before any hipGraph
-    capture, so a replayed step carries no extra fill -- which means calls on ONE device must be stream-ordered with respect to each
-    other (they are: the step closures issue everything on the current stream)."""
+    (partials + a ticket it re-arms itself) is one persistent buffer per device (``_penalty_workspace``: created eagerly by
+    ``KerasAdam.set_l2``, never inside a capture), so a replayed step carries no extra fill -- which means calls on ONE device must
+    be stream-ordered with respect to each other (they are: the step closures issue everything on the current stream)."""
     params, coefficients = list(params), [float(c) for c in coefficients]
     n = len(params)
     if n == 0:
@@ -136,9 +164,7 @@ def l2_penalty(params, coefficients) -> torch.Tensor:
     if not all(p.is_cuda and p.device == dev and p.dtype == torch.float32 and p.is_contiguous() for p in params) or n > 16:
         raise ValueError("l2_penalty: contiguous fp32 tensors on one GPU (at most 16) expected")
     L = _capi.lib()
-    ws = _PENALTY_WS.get(dev)
-    if ws is None:
-        ws = _PENALTY_WS[dev] = torch.zeros(int(L.h2gcn_l2_penalty_workspace_bytes()) // 8 + 1, dtype=torch.float64, device=dev)
+    ws = _penalty_workspace(dev)
     out = torch.empty((), dtype=torch.float32, device=dev)
     arr = C.c_void_p * n
     with torch.cuda.device(dev):

@@ -47,9 +47,12 @@ def enable_rccl_debug_log(directory: str) -> None:
     """Have RCCL write what it decides at communicator set-up (topology graph, channels, transports) and per collective
     (algorithm / protocol) into one FILE per process under ``directory`` -- never to stdout/stderr.  Must run before the
     process group is created.  Ring-vs-direct is what decides the 8-GPU outcome of the per-layer all-gather
-    (SURVEY.md §7), so a multi-rank run keeps this next to its number; existing NCCL_DEBUG* settings are respected."""
+    (SURVEY.md §7), so a multi-rank run keeps this next to its number.  A level below INFO that is already in the environment
+    (this image exports NCCL_DEBUG=VERSION, which makes RCCL print its banner to STDOUT) is raised to INFO; a more verbose
+    level, a subsystem list or a file name the caller chose are kept."""
     os.makedirs(directory, exist_ok=True)
-    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE", "ABORT"):
+        os.environ["NCCL_DEBUG"] = "INFO"
     os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING")
     os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(directory, "rccl.%h.%p"))
 
@@ -477,7 +480,9 @@ class PipelinedHopAggregation:
             env = os.environ.get("H2GCN_HALO")
             if env is not None:
                 halo = {"0": False, "1": True}.get(env, halo)
-            if halo and exchange == "ipc_kernel" and all(w % 4 == 0 for w in widths) and hasattr(plan, "colidx"):
+            from . import _capi
+            if (halo and exchange == "ipc_kernel" and all(w % 4 == 0 for w in widths) and hasattr(plan, "colidx")
+                    and _capi.has("h2gcn_xchg_allgather_pull_rows")):
                 lists, named, remote = self._halo_lists(plan)
                 self.halo_ratio = named / max(remote, 1)
                 if halo is True or self.halo_ratio < 0.9:

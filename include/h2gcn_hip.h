@@ -107,7 +107,13 @@ int h2gcn_device_count(void);
  * (reference h2gcn/datasets/_dataset.py:559-576) as far as the device side is concerned -- the normalised
  * values themselves are computed by the caller.
  *
- *   n_hops            1..H2GCN_MAX_HOPS  (H2GCN uses 2: exact-1-hop and exact-2-hop neighbourhoods)
+ *   n_hops            1..H2GCN_MAX_HOPS  (H2GCN uses 2: exact-1-hop and exact-2-hop neighbourhoods; the reference takes
+ *                     as many groups as --adj_nhood lists).  Every hop count gives the same per-row summation tree.
+ *                     Scheduling above 4 SELECTED hops: the forward keeps its per-hop short-segment lists at any
+ *                     count; the adjoint (SUM mode: one list of the rows that are short in every selected hop, staged
+ *                     through LDS per hop) keeps its list for selections of up to 4 hops and walks the row tiles for
+ *                     5..8 -- a scheduling difference only, the bits do not change.  rows_per_wave is at most 7, so
+ *                     (rows_per_wave + 1) * n_hops never exceeds the 64 row pointers one wave-wide load holds.
  *   n_rows, n_cols    matrix shape; n_rows != n_cols is allowed (row-partitioned shards: n_rows = N/P)
  *   rowptr_dev[k], colidx_dev[k], vals_dev[k]   CSR of hop k, device pointers (see layout above)
  *   opts              NULL for defaults
@@ -189,6 +195,15 @@ int h2gcn_plan_segment_classes(const h2gcn_plan_t* plan, uint32_t hop_mask, int 
  * scratch copy and segment walk (rows with >= long_row_threshold nonzeros: the same tree per wave over the wave's
  * 64-neighbour chunks, wave totals added in order).  The bits of Y depend only on the row's nonzeros, X and
  * long_row_threshold: a row-partitioned multi-GPU run equals the single-GPU run bit-for-bit.
+ *
+ * hipGraph capture: a launch may be issued on a capturing stream, with one proviso.  The device-side row lists of a hop
+ * selection (its long-segment list; its per-class lists once a launch is list-driven) are built by the FIRST launch of
+ * that selection -- a device allocation and a synchronous upload under the plan's lock, neither of which may happen inside
+ * a capture.  The all-hops selection is prepared by h2gcn_plan_create; for any other hop_mask (and for the adjoint, per
+ * hop_mask) run the launch once eagerly at the width you are going to capture -- a warm-up step -- before capturing it.
+ * A launch that would have to build a list while its stream is capturing returns H2GCN_ERR_INVALID_ARGUMENT with that
+ * advice (it never falls back to another walk silently: the graph would replay the slower schedule for ever).  The same
+ * first launch is also where an eager caller pays the one-off host synchronisation.
  */
 int h2gcn_spmm_hops_f32(const h2gcn_plan_t* plan, uint32_t hop_mask, const float* X_dev, int64_t ldx,
                         int32_t d, float* Y_dev, int64_t ldy_row, int64_t ldy_hop, void* stream);

@@ -33,3 +33,45 @@ def test_bench_refuses_to_run_without_a_gpu():
         return
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True)
     assert r.returncode != 0 and "no CPU fallback" in (r.stdout + r.stderr)
+
+
+RCCL_LOG = """\
+host:123:123 [0] NCCL INFO NCCL version 2.22.3+hip6.4 HEAD:abc
+host:123:140 [0] NCCL INFO Channel 00/16 :    0   1   2   3   4   5   6   7
+host:123:140 [0] NCCL INFO Channel 01/16 :    0   1   2   3   4   5   6   7
+host:123:140 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1 [1] 1/-1/-1->0->-1
+host:123:140 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC
+host:123:140 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC
+host:123:140 [0] NCCL INFO Channel 00/0 : 0[0] -> 2[2] via SHM/direct/direct
+host:123:140 [0] NCCL INFO Connected all rings
+host:123:140 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels, 2 p2p channels per peer
+host:123:140 [0] NCCL INFO comm 0x55 rank 0 nranks 8 cudaDev 0 nvmlDev 0 busId 5000 commId 0xabc - Init COMPLETE
+host:123:140 [0] NCCL INFO AllGather: 39321600 Bytes -> Algo 1 proto 2 time 310.0
+host:123:140 [0] NCCL INFO AllGather: 39321600 Bytes -> Algo 1 proto 2 time 310.0
+host:123:140 [0] NCCL INFO AllGather: 19660800 Bytes -> Algo 1 proto 2 time 160.0
+"""
+
+
+def test_rccl_log_summary(tmp_path, monkeypatch):
+    """`config.diagnostics.rccl` of an N > 1 line: <= 10 strings out of RCCL's per-process debug file -- version, communicator
+    size, channels, transports (P2P/IPC = xGMI vs SHM), the distinct algorithm/protocol picks."""
+    import os
+    import socket
+
+    from h2gcn_amd.partition import enable_rccl_debug_log, summarize_rccl_log
+
+    for k in ("NCCL_DEBUG_SUBSYS", "NCCL_DEBUG_FILE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("NCCL_DEBUG", "VERSION")          # what the GPU image exports: too quiet, and it prints to stdout
+    enable_rccl_debug_log(str(tmp_path))
+    assert os.environ["NCCL_DEBUG"] == "INFO" and os.environ["NCCL_DEBUG_FILE"].startswith(str(tmp_path))
+    assert summarize_rccl_log(str(tmp_path)) == []                       # no file yet
+    (tmp_path / f"rccl.{socket.gethostname()}.{os.getpid()}").write_text(RCCL_LOG)
+    got = summarize_rccl_log(str(tmp_path))
+    assert 0 < len(got) <= 10
+    text = "\n".join(got)
+    assert "version 2.22.3" in text and "nranks 8" in text and "ring channels: 16" in text
+    assert "P2P/IPC x2" in text and "SHM/direct/direct x1" in text
+    assert text.count("AllGather") == 2 and "algo 1" in text             # distinct picks only
+    for k in ("NCCL_DEBUG", "NCCL_DEBUG_SUBSYS", "NCCL_DEBUG_FILE"):
+        monkeypatch.delenv(k, raising=False)

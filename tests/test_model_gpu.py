@@ -140,7 +140,20 @@ def test_syn_products_h2gcn2_logits(tmp_path):
     want, want_tagged, trace = om.forward(_enc(setup), sp.csr_matrix(feats), ohops, weights, return_tagged=True)
     scale = max(1.0, float(np.abs(want).max()))
     assert np.abs(logits.cpu().numpy() - want).max() <= 1e-5 * scale
+    # r1 (tag "2": the d = 64 launch) and r2 (untagged: the d = 128 launch, the leading 256 columns of the concat [r2|r0|r1])
+    # EACH on its own, not only through the logits.  Tolerance: 1e-5 x max(1, max|reference|) -- the features are not
+    # row-normalised here (`--no_feature_normalize`), so activations are O(10), not O(1); BASELINE.md section 4 row 2 says so
     assert np.abs(tagged["2"].cpu().numpy() - want_tagged["2"]).max() <= 1e-5 * max(1.0, np.abs(want_tagged["2"]).max())
+    kinds = [k for k, _ in setup]
+    second_v, last_c = [i for i, k in enumerate(kinds) if k == "V"][1], [i for i, k in enumerate(kinds) if k == "C"][-1]
+    r2_want = np.asarray(trace[second_v])
+    assert r2_want.shape == (10000, 256) and np.array_equal(np.asarray(trace[last_c])[:, :256], r2_want)
+    with torch.no_grad():
+        cat = model(None, fplan, plan, return_before=last_c + 1)
+    assert cat.shape == (10000, 448)
+    r2_got = cat[:, :256].cpu().numpy()
+    assert np.abs(r2_got - r2_want).max() <= 1e-5 * max(1.0, np.abs(r2_want).max()), np.abs(r2_got - r2_want).max()
+    assert np.abs(cat[:, 320:].cpu().numpy() - want_tagged["2"]).max() <= 1e-5 * max(1.0, np.abs(want_tagged["2"]).max())
     assert plan.nnz == [h.nnz for h in ohops]
     # dense-ish features take the GEMM path (dense operand, rocBLAS) -- same logits
     torch.manual_seed(1)

@@ -637,6 +637,102 @@ def test_csr_adaptive_segment_classes_in_one_launch(kinds, d):
     assert np.array_equal(plan.spmm(xo).cpu().numpy(), og.gcn_layer_tree(hops, x[:, : d - 3]))
 
 
+@pytest.mark.parametrize("kinds", [("sparse", "mixed", "sparse", "sparse", "sparse"),
+                                   ("sparse", "mixed", "sparse", "dense", "sparse", "sparse", "mixed", "sparse")])
+@pytest.mark.parametrize("d", [64, 100])
+def test_five_and_eight_hop_groups(kinds, d):
+    """`--adj_nhood` takes any number of hop groups (reference h2gcn/datasets/_dataset.py:559-576); the header admits
+    H2GCN_MAX_HOPS = 8.  With 5 and 8 hops, short / medium / long segments side by side: forward, hop subsets, adjoint and the
+    accumulating adjoint carry the bits of the canonical tree for the default schedule (0), forced lists (6) and the plain
+    wave walk (3).  Above kShortSumHops = 4 selected hops the SUM-mode (adjoint) launch has no row lists and walks the
+    tiles (h2gcn_capi.hip, build_class_lists); a 4-hop subset of the same plan gets its lists back.  rows_per_wave = 7 with
+    8 hops is the largest (rows_per_wave + 1) * n_hops = 64 row-pointer load one wave holds."""
+    from h2gcn_amd import HopPlan
+
+    H = len(kinds)
+    rng = np.random.default_rng(1000 * H + d)
+    n = 1500
+    hops = _mixed_hops(rng, n, kinds)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    w = rng.uniform(-1, 1, (n, H, d)).astype(np.float32)
+    xt, wt = torch.from_numpy(x).to(dev()), torch.from_numpy(w).to(dev())
+    tree, tree_t = og.gcn_layer_tree(hops, x), og.gcn_layer_grad_tree(hops, w, n)
+    assert_close(tree, hops, x)
+    want_t = sum(h.T.astype(np.float64) @ w[:, k, :].astype(np.float64) for k, h in enumerate(hops))
+    mag_t = sum(abs(h).T.astype(np.float64) @ np.abs(w[:, k, :]).astype(np.float64) for k, h in enumerate(hops))
+    assert (np.abs(tree_t - want_t) <= 1e-5 * np.maximum(1.0, mag_t)).all()
+    sparse = [k for k, kind in enumerate(kinds) if kind == "sparse"]          # 4 of 5 / 5 of 8 hops: every segment short
+    sub4, sub5 = [0, 1, H - 2, H - 1], [0, 1, 2, H - 2, H - 1]
+    for variant in (0, 6, 3):
+        for rpw in (0, 7):
+            plan = HopPlan.from_scipy(hops, dev(), build_transpose=True, variant=variant, rows_per_wave=rpw)
+            assert plan.n_hops == H
+            y = plan.spmm(xt)
+            assert y.shape == (n, H, d) and np.array_equal(y.cpu().numpy(), tree), (variant, rpw)
+            dx = plan.spmm_t(wt)
+            assert np.array_equal(dx.cpu().numpy(), tree_t), (variant, rpw, "adjoint")
+            for sel in (sub4, sub5, sparse[:4], sparse, [H - 1]):
+                hs = [hops[k] for k in sel]
+                assert np.array_equal(plan.spmm(xt, hops=sel).cpu().numpy(), og.gcn_layer_tree(hs, x)), (variant, rpw, sel)
+                ws = wt[:, sel].contiguous()
+                assert np.array_equal(plan.spmm_t(ws, hops=sel).cpu().numpy(), og.gcn_layer_grad_tree(hs, w[:, sel], n)), (variant, rpw, sel)
+            # accumulate into a strided slot of a wider gradient buffer: exactly old + sum, nothing else touched
+            wide = torch.from_numpy(rng.uniform(-1, 1, (n, d + 5)).astype(np.float32)).to(dev())
+            before = wide.clone()
+            plan.spmm_t(wt, out=wide[:, 2:2 + d], accumulate=True)
+            assert torch.equal(wide[:, 2:2 + d], before[:, 2:2 + d] + dx)
+            assert torch.equal(wide[:, :2], before[:, :2]) and torch.equal(wide[:, 2 + d:], before[:, 2 + d:])
+            if variant == 6 and d % 4 == 0:
+                # the forward keeps one list per selected hop at any hop count; the adjoint (one list of the rows that are short
+                # in EVERY selected hop) only for selections of at most 4 hops
+                assert plan.segment_classes(d)["listed"] > 0
+                assert plan.segment_classes(d, hops=sparse[:4], adjoint=True)["listed"] > 0
+                if len(sparse) > 4:
+                    assert plan.segment_classes(d, hops=sparse, adjoint=True)["listed"] == 0
+                assert plan.segment_classes(d, adjoint=True)["listed"] == 0
+
+
+def test_first_launch_of_a_hop_selection_inside_a_capture_is_refused_with_advice():
+    """include/h2gcn_hip.h, "hipGraph capture": the device lists of a hop selection are built by its first launch (allocation
+    + synchronous upload); on a capturing stream that launch is refused with a message that names the remedy -- never a
+    capture failure deep inside HIP, never a silent fall-back to a slower walk.  After one eager launch the same call captures
+    and replays with the eager bits."""
+    from h2gcn_amd import HopPlan
+    from h2gcn_amd._capi import H2GCNError
+
+    rng = np.random.default_rng(3)
+    n, d = 1500, 64
+    hops = _mixed_hops(rng, n, ("sparse", "mixed", "dense"))        # "mixed" has segments of 256 and 700 nonzeros: a long list
+    plan = HopPlan.from_scipy(hops, dev(), build_transpose=True)
+    xt = torch.from_numpy(rng.uniform(-1, 1, (n, d)).astype(np.float32)).to(dev())
+    wt = torch.from_numpy(rng.uniform(-1, 1, (n, 1, d)).astype(np.float32)).to(dev())
+    y, dx = torch.zeros((n, 1, d), device=dev()), torch.zeros((n, d), device=dev())
+    plan.spmm(xt)                                                   # the all-hops selection: prepared at plan creation
+    torch.cuda.synchronize()
+    errors = {}
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for name, fn in (("forward", lambda: plan.spmm(xt, hops=[1], out=y)), ("adjoint", lambda: plan.spmm_t(wt, hops=[1], out=dx))):
+            try:
+                fn()
+            except H2GCNError as e:
+                errors[name] = str(e)
+    # the forward selection has long segments (a list to build): refused.  The adjoint's A_1^T may have none (the long rows of A_1
+    # spread over its columns): then there is nothing to build and the launch is simply captured -- either outcome is legitimate
+    assert "forward" in errors and all("captured" in e and "warm-up" in e for e in errors.values()), errors
+    want, want_t = plan.spmm(xt, hops=[1]), plan.spmm_t(wt, hops=[1])     # eager once: builds the lists
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        plan.spmm(xt, hops=[1], out=y)
+        plan.spmm_t(wt, hops=[1], out=dx)
+    y.zero_(); dx.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, want) and torch.equal(dx, want_t)
+    assert np.array_equal(want.cpu().numpy(), og.gcn_layer_tree([hops[1]], xt.cpu().numpy()))
+
+
 @pytest.mark.parametrize("n,d", [(300_000, 128), (1_200_000, 64)])
 def test_list_driven_launch_at_scale_has_the_bits_of_the_tile_walk(n, d):
     """Mixed segment classes at a size where the list-driven launch uses everything it has -- hundreds of thousands of listed

@@ -3,8 +3,11 @@ row-partitioned path uses on a multi-GPU node (run by tests/test_multirank_gpu.p
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.getcwd())
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29555"), RANK="0", WORLD_SIZE="1")
+import json, tempfile
 from h2gcn_amd.partition import init_rccl_process_group, _all_gather_rows, _all_gather_rows_p2p, _reduce_scatter_rows
+from h2gcn_amd.partition import enable_rccl_debug_log, summarize_rccl_log
 torch.cuda.set_device(0); dev = torch.device("cuda", 0)
+log_dir = tempfile.mkdtemp(prefix="h2gcn_rccl_", dir="/tmp"); enable_rccl_debug_log(log_dir)   # as bench.py does at N > 1
 init_rccl_process_group(dev, 120.0)  # with the collective timeout bench.py passes
 send = torch.arange(12, dtype=torch.float32, device=dev).view(3, 4); full = torch.zeros_like(send)
 _all_gather_rows(full, send); assert torch.equal(full, send)
@@ -23,5 +26,12 @@ objs = [None]; dist.all_gather_object(objs, b"blob")            # the bootstrap 
 assert objs == [b"blob"]
 from h2gcn_amd.partition import IpcExchange
 x = IpcExchange(2, 4096, dev); x.close()                          # world 1: create / export / destroy under the nccl backend
-torch.cuda.synchronize(); dist.barrier(); print("rccl single-rank ok", dist.get_backend())
+torch.cuda.synchronize(); dist.barrier()
+summary = summarize_rccl_log(log_dir)
+print(json.dumps({"rccl": summary}))          # what bench.py puts under config.diagnostics.rccl (file log only)
+if not summary:   # say why: which files exist, what RCCL was told
+    import glob
+    print("no RCCL log found:", {k: v for k, v in os.environ.items() if k.startswith("NCCL_") or k.startswith("RCCL_")},
+          "dir:", os.listdir(log_dir), "tmp:", glob.glob("/tmp/rccl*") + glob.glob("/tmp/*/rccl*"), file=sys.stderr)
+print("rccl single-rank ok", dist.get_backend())
 dist.destroy_process_group()
