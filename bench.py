@@ -265,13 +265,14 @@ def dry_exchange(a, world, rank, device, backend, to_stderr=False):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item() > 0)
 
-    exchanges = [a.exchange] if a.exchange else os.environ.get("H2GCN_BENCH_EXCHANGES", "allgather,p2p,ipc_engine,ipc_kernel").split(",")
-    for ex in exchanges:
+    for ex in exchange_families(a):
         for spec in ([a.chunks] if a.chunks else ["1", "2"]):
             key = f"{ex}/{spec}"
             if ex == "ipc_engine" and world - 1 > hwq - 2:
                 rejected[key] = f"copy-engine pulls park {world - 1} spin-wait kernels on hardware queues; GPU_MAX_HW_QUEUES = {hwq} leaves {hwq - 2}"
                 continue
+            if to_stderr:   # (part of a measuring run: on record which form is in flight, should it take the job down)
+                progress({"starting": key, "stage": "first contact"}, rank)
             cand, why = None, None
             try:
                 cand = PipelinedHopAggregation(plan, n, d, parse_chunks(spec, d), device, exchange=ex, partition=part)
@@ -281,6 +282,8 @@ def dry_exchange(a, world, rank, device, backend, to_stderr=False):
                 rejected[key] = why or "construction failed on another rank"
                 if cand is not None and cand.ipc is not None:
                     cand.ipc._destroy_local()
+                if to_stderr:
+                    progress({"finished": key, "stage": "first contact"}, rank)
                 continue
             try:
                 cand(x_local)                      # stages the shard and runs one full step (exchange + SpMM)
@@ -305,6 +308,8 @@ def dry_exchange(a, world, rank, device, backend, to_stderr=False):
                 cand.close()
             except Exception:  # noqa: BLE001
                 pass
+            if to_stderr:
+                progress({"finished": key, "stage": "first contact"}, rank)
     report = {"dry_exchange": table, "rejected": rejected, "n_gpus": world, "shard_bytes": per * d * 4,
               "dist_backend": backend, "GPU_MAX_HW_QUEUES": hwq,
               "note": "1 MiB shards: latency-dominated rates, a smoke test of every exchange form -- not a bandwidth figure"}
@@ -392,6 +397,17 @@ def self_launch(n_ranks):
                       "error": f"torch.distributed.run exited with {r.returncode} without a result line",
                       "stdout_tail": r.stdout[-500:]}), flush=True)
     return r.returncode or 1
+
+
+EXCHANGE_ORDER = {"allgather": 0, "ipc_kernel": 1, "ipc_engine": 2, "p2p": 3}   # safest first (see main)
+
+
+def exchange_families(a):
+    """The exchange forms of this run, SAFEST FIRST: --exchange, else $H2GCN_BENCH_EXCHANGES, else all four; minus what a retry of
+    the supervisor's ladder excludes ($H2GCN_BENCH_EXCLUDE_EXCHANGES: the form that was in flight when an attempt died)."""
+    fams = [a.exchange] if a.exchange else os.environ.get("H2GCN_BENCH_EXCHANGES", "allgather,p2p,ipc_engine,ipc_kernel").split(",")
+    gone = set(filter(None, os.environ.get("H2GCN_BENCH_EXCLUDE_EXCHANGES", "").split(",")))
+    return sorted((f for f in fams if f and f not in gone), key=lambda f: EXCHANGE_ORDER.get(f, 9))
 
 
 def parse_chunks(spec, d):
@@ -559,15 +575,14 @@ def main():
         layer = PipelinedHopAggregation(plan, n, d, chunks, device)
         exchange = None
     else:
-        exchanges = [a.exchange] if a.exchange else os.environ.get(
-            "H2GCN_BENCH_EXCHANGES", "allgather,p2p,ipc_engine,ipc_kernel").split(",")
+        exchanges = exchange_families(a)
         # every chunk width builds the canonical summation tree, so the checksum of Y is the same for every candidate and
         # equal to the 1-GPU line's; 32-column chunks (a short exposed head of the exchange) run as masked 64-column slices
         chunk_specs = [a.chunks] if a.chunks else ["1", "2", "4", "32+32+64"]
         # SAFEST FIRST: one ncclAllGather per chunk and the library's own copy-kernel pulls are timed before anything whose
         # first contact with a second device could take the job down (grouped send/recv last); whatever is on record when
         # a later candidate dies is what the supervisor's line carries
-        order = {"allgather": 0, "ipc_kernel": 1, "ipc_engine": 2, "p2p": 3}
+        order = EXCHANGE_ORDER
         pairs = sorted(((ex, spec) for ex in exchanges for spec in chunk_specs),
                        key=lambda es: (0 if es[1] == "2" and order.get(es[0], 9) < 2 else 1, order.get(es[0], 9), chunk_specs.index(es[1])))
         calib_budget = float(os.environ.get("H2GCN_BENCH_CALIBRATION_BUDGET_S", "180"))
@@ -626,6 +641,9 @@ def main():
                 rejected[key] = f"copy-engine pulls need {world - 1} hardware queues besides the main and exchange ones; GPU_MAX_HW_QUEUES = {hwq}"
                 continue
             cand, why = None, None
+            progress({"starting": key, "stage": "calibration"}, rank)   # which form is in flight, should it take the job down
+            if key == os.environ.get("H2GCN_BENCH_FAIL_IN_CANDIDATE"):
+                injected_failure("candidate", rank)
             try:
                 cand = PipelinedHopAggregation(plan, n, d, widths, device, exchange=ex)
             except Exception as e:  # noqa: BLE001 -- unavailable on this node/backend: not a candidate
@@ -634,6 +652,8 @@ def main():
                 rejected[key] = why or "construction failed on another rank"
                 if cand is not None:
                     cand.ipc = None if cand.ipc is None else cand.ipc._destroy_local()
+                progress({"calibration": key, "rejected": rejected[key], "n_gpus": world}, rank)
+                progress({"finished": key, "stage": "calibration"}, rank)
                 continue
             why = exchange_is_exact(cand)
             if not all_ok(why is None):
@@ -643,11 +663,13 @@ def main():
                     cand.close()       # collective: every rank is here
                 except Exception:  # noqa: BLE001
                     pass
+                progress({"finished": key, "stage": "calibration"}, rank)
                 continue
             cands[key] = (timed_ms(lambda: cand(x_local, out=y), 3), cand, ex, spec)
             # on record at once: if a later candidate takes the job down, what was measured survives (stderr + supervisor)
             progress({"calibration": key, "ms_per_step": cands[key][0], "n_gpus": world, "edges_per_s": sum(nnz_global) / (cands[key][0] * 1e-3),
                       "note": "3-step calibration timing, not the K-step measurement"}, rank)
+            progress({"finished": key, "stage": "calibration"}, rank)
             if len(cands) == 1:
                 injected_failure("calibration", rank)
         del x_alt_local, x_ref

@@ -10,9 +10,10 @@ store (the launcher's own TCPStore on MASTER_ADDR:MASTER_PORT when torch.distrib
 hosted by rank 0's supervisor) and walk down a ladder of attempts, each a fresh set of worker processes on a fresh
 rendezvous port:
 
-    attempt 0   what was asked for: first-contact table, calibration over every exchange x chunking, K timed steps
-    attempt 1   conservative: one ncclAllGather per chunk, 2 chunks, no first-contact table, no calibration sweep
-    attempt 2   no RCCL at all: gloo bootstrap + the library's own IPC copy-kernel exchange, 2 chunks
+    requested      what was asked for: first-contact table, calibration over every exchange x chunking, K timed steps
+    exclude        (at most twice) the same sweep WITHOUT the exchange form that was in flight when the attempt died
+    conservative   one ncclAllGather per chunk, 2 chunks, no first-contact table, no calibration sweep
+    no_rccl        no RCCL at all: gloo bootstrap + the library's own IPC copy-kernel exchange, 2 chunks
 
 The first attempt whose rank 0 produces a line with a value wins -- that line exists only after the max-over-ranks of
 the K timed steps, so a rank that gets stuck or dies in the tear-down after it no longer matters (the workers are given
@@ -41,15 +42,46 @@ from pathlib import Path
 METRIC = "aggregated edges/sec (1+2-hop SpMM)"
 USAGE_ERROR = 64   # bench.py's exit code for a command line that cannot run under any schedule (EX_USAGE)
 
-#: the ladder: (name, environment overrides of the workers of that attempt)
-LADDER = (
-    ("as requested", {}),
-    ("conservative: ncclAllGather, 2 chunks, no calibration sweep",
-     {"H2GCN_BENCH_FORCE_EXCHANGE": "allgather", "H2GCN_BENCH_FORCE_CHUNKS": "2", "H2GCN_BENCH_SKIP_DRY": "1"}),
-    ("no RCCL: gloo bootstrap + IPC copy-kernel exchange, 2 chunks",
-     {"H2GCN_BENCH_FORCE_EXCHANGE": "ipc_kernel", "H2GCN_BENCH_FORCE_CHUNKS": "2", "H2GCN_BENCH_SKIP_DRY": "1",
-      "H2GCN_DIST_BACKEND": "gloo"}),
-)
+#: the rungs of the ladder: what the workers of an attempt are told (environment overrides)
+RUNG_REQUESTED = {"rung": "requested", "name": "as requested", "env": {}, "excluded": []}
+RUNG_CONSERVATIVE = {"rung": "conservative", "name": "conservative: ncclAllGather, 2 chunks, no calibration sweep", "excluded": [],
+                     "env": {"H2GCN_BENCH_FORCE_EXCHANGE": "allgather", "H2GCN_BENCH_FORCE_CHUNKS": "2", "H2GCN_BENCH_SKIP_DRY": "1"}}
+RUNG_NO_RCCL = {"rung": "no_rccl", "name": "no RCCL: gloo bootstrap + IPC copy-kernel exchange, 2 chunks", "excluded": [],
+                "env": {"H2GCN_BENCH_FORCE_EXCHANGE": "ipc_kernel", "H2GCN_BENCH_FORCE_CHUNKS": "2", "H2GCN_BENCH_SKIP_DRY": "1",
+                        "H2GCN_DIST_BACKEND": "gloo"}}
+MAX_RUNGS = 5            # requested + up to 2 exclusions + conservative + no-RCCL
+
+
+def next_rung(history):
+    """What to try after the attempts in `history` (rank 0 decides, the others are told).  If the worker's record shows WHICH
+    exchange family was in flight when the attempt died (`in_flight_family`: the last candidate that was started and never
+    finished -- e.g. the grouped send/recv form on its first contact with a second device), the sweep is repeated without that
+    family, so that the best of the remaining schedules is still found (at most twice); then the conservative rung; then the
+    rung that does not touch RCCL.  An attempt that died with the plain ncclAllGather in flight skips straight to the last."""
+    tried = [h["rung"] for h in history]
+    last = history[-1]
+    fam, excluded = last.get("in_flight_family"), set(last.get("excluded") or [])
+    if last["rung"] in ("requested", "exclude") and fam and fam != "allgather" and fam not in excluded and tried.count("exclude") < 2:
+        ex = sorted(excluded | {fam})
+        return {"rung": "exclude", "excluded": ex,
+                "name": f"as requested without the exchange form(s) {', '.join(ex)} (in flight when an attempt died); no first-contact table",
+                "env": {"H2GCN_BENCH_EXCLUDE_EXCHANGES": ",".join(ex), "H2GCN_BENCH_SKIP_DRY": "1"}}
+    if "conservative" not in tried and "no_rccl" not in tried and fam != "allgather":
+        return RUNG_CONSERVATIVE
+    if "no_rccl" not in tried:
+        return RUNG_NO_RCCL
+    return None
+
+
+def in_flight_family(entries):
+    """Exchange family of the last candidate the worker STARTED (first-contact table or calibration) and never finished."""
+    open_key = None
+    for e in entries:
+        if "starting" in e:
+            open_key = e["starting"]
+        elif e.get("finished") == open_key:
+            open_key = None
+    return None if open_key is None else str(open_key).split("/")[0]
 
 
 def _free_port() -> int:
@@ -190,7 +222,9 @@ def supervise(argv, rank: int, world: int) -> int:
     budget0 = budget_first
     grace = float(os.environ.get("H2GCN_BENCH_PEER_FAILURE_GRACE_S", "8"))       # how long a worker outlives a failed peer
     teardown = float(os.environ.get("H2GCN_BENCH_TEARDOWN_GRACE_S", "20"))       # ... and how long it may take to exit after the line
-    n_attempts = max(1, min(len(LADDER), int(os.environ.get("H2GCN_BENCH_MAX_ATTEMPTS", str(len(LADDER))))))
+    n_attempts = max(1, min(MAX_RUNGS, int(os.environ.get("H2GCN_BENCH_MAX_ATTEMPTS", str(MAX_RUNGS)))))
+    total_budget = float(os.environ.get("H2GCN_BENCH_TOTAL_BUDGET_S", "1500"))      # all rungs together
+    t_start = time.monotonic()
     store = _Store(rank, world, timeout_s=max(60.0, budget0))
     tmp = Path(tempfile.mkdtemp(prefix=f"h2gcn_bench_r{rank}_", dir="/tmp"))
     worker_cmd = os.environ.get("H2GCN_BENCH_WORKER_CMD")     # test hook: a JSON list that replaces `python bench.py <argv>`
@@ -212,8 +246,16 @@ def supervise(argv, rank: int, world: int) -> int:
     history = []          # rank 0: one entry per failed attempt
     final = 1
     for k in range(n_attempts):
-        name, overrides = LADDER[k]
-        budget0 = budget_first if k == 0 else budget_retry
+        if k == 0:
+            rung = RUNG_REQUESTED
+        else:
+            told = store.get(f"a{k}/rung", 60.0)
+            if told is None:
+                break
+            rung = json.loads(told)
+        name, overrides = rung["name"], rung["env"]
+        remaining = total_budget - (time.monotonic() - t_start)
+        budget0 = max(30.0, min(budget_first if k == 0 else budget_retry, remaining))
         # a fresh rendezvous port per attempt: the dead attempt's keys (ncclUniqueId, gloo addresses) must not be found
         if rank == 0:
             store.set(f"a{k}/port", _free_port())
@@ -327,24 +369,31 @@ def supervise(argv, rank: int, world: int) -> int:
         # what the store saw first is often a SYMPTOM (a peer's connection reset); a rank that died of a signal nobody here sent
         # (SIGABRT: the watchdog; SIGSEGV; the OOM killer's SIGKILL arrives as -9 too, but so do our own kills) is the cause
         died = [f"rank {q}: {_describe_rc(v)}" for q, v in rcs.items() if v is not None and v < 0 and -v not in (signal.SIGTERM, signal.SIGKILL)]
-        entry = {"attempt": k, "schedule": name,
+        attempt_entries = [e for e in _progress_entries(tmp / "progress.jsonl") if e.get("attempt", k) == k]
+        entry = {"attempt": k, "schedule": name, "rung": rung["rung"], "excluded": rung.get("excluded", []),
+                 "in_flight_family": in_flight_family(attempt_entries),
                  "ranks": {str(q): ("ok" if v == 0 else _describe_rc(v)) for q, v in rcs.items()},
                  "first_failure": died[0] if died else store.get(f"a{k}/failed", 0.1),
-                 "calibration": [e for e in _progress_entries(tmp / "progress.jsonl") if e.get("attempt", k) == k]}
+                 "calibration": [e for e in attempt_entries if "starting" not in e and "finished" not in e]}
         if line is not None and line.get("error"):
             entry["error_line"] = line["error"]
         history.append(entry)
         print(json.dumps({"supervisor": f"attempt {k} ({name}) failed", "ranks": entry["ranks"], "first_failure": entry["first_failure"]}),
               file=sys.stderr, flush=True)
         # exit code 64 on every rank = the command line itself is wrong (bench.py's usage errors): no schedule will fix that
-        last = k == n_attempts - 1 or all(v == USAGE_ERROR for v in rcs.values())
-        store.set(f"a{k}/verdict", "fail" if last else "retry")
-        if last:
+        nxt = None
+        out_of_time = total_budget - (time.monotonic() - t_start) < 45.0
+        if k < n_attempts - 1 and not out_of_time and not all(v == USAGE_ERROR for v in rcs.values()):
+            nxt = next_rung(history)
+        if nxt is not None:
+            store.set(f"a{k + 1}/rung", json.dumps(nxt))
+        store.set(f"a{k}/verdict", "retry" if nxt is not None else "fail")
+        if nxt is None:
             break
     if rank == 0 and final != 0:
         partial = [e for h in history for e in h.get("calibration", [])]
         print(json.dumps({"metric": METRIC, "value": None, "unit": "edges/s", "n_gpus": world,
-                          "error": f"every attempt failed ({len(history)} of {n_attempts}): "
+                          "error": f"every attempt failed ({len(history)}): "
                                    + "; ".join(f"[{h['attempt']}] {h.get('error_line') or h.get('first_failure') or h.get('error') or h.get('ranks')}"
                                                for h in history),
                           "attempts": history, "partial": partial}), flush=True)

@@ -656,13 +656,28 @@ def test_bench_survives_a_rank_that_aborts(tmp_path):
     _keep("bench_shared_gpu_rank_abort_n2.json", out)
 
 
+def test_bench_leaves_out_the_exchange_form_that_was_in_flight_when_a_rank_died(tmp_path):
+    """Rank 1 dies INSIDE the ipc_kernel/2 candidate (started, never finished, in rank 0's record).  The next rung repeats the
+    calibration sweep without that exchange form instead of falling straight back to the single conservative schedule."""
+    lines, err, rcs = _run_supervised(2, ["--chunks", "2"], {"H2GCN_BENCH_ABORT_RANK": "1", "H2GCN_BENCH_FAIL_STAGE": "candidate",
+                                                             "H2GCN_BENCH_FAIL_IN_CANDIDATE": "ipc_kernel/2"})
+    assert len(lines) == 1 and rcs == [0, 0], (lines, err[-3000:])
+    out = json.loads(lines[0])
+    diag = out["config"]["diagnostics"]
+    assert out["value"] > 0 and out["config"]["checksum_matches_n1"] is True and diag["exchange"] == "allgather"
+    first = diag["first_attempt"]
+    assert first["in_flight_family"] == "ipc_kernel" and first["ranks"]["1"] == "killed by SIGABRT"
+    assert [e["calibration"] for e in first["calibration"] if "ms_per_step" in e] == ["allgather/2"]
+    assert "ipc_kernel" in diag["attempts"][1]["schedule"] and diag["attempts"][1]["result"] == "ok"
+
+
 def test_bench_rank_aborting_in_every_attempt_is_one_error_line(tmp_path):
     """The same injection honoured on every rung of the ladder: one error line (value null) that still carries every
     calibration entry that completed, as `partial`."""
     lines, err, rcs = _run_supervised(2, [], {"H2GCN_BENCH_ABORT_RANK": "1", "H2GCN_BENCH_FAIL_ATTEMPTS": "0,1,2"})
     assert len(lines) == 1 and rcs[0] != 0, (lines, err[-3000:])
     out = json.loads(lines[0])
-    assert out["value"] is None and "every attempt failed (3 of 3)" in out["error"] and len(out["attempts"]) == 3
+    assert out["value"] is None and "every attempt failed (3)" in out["error"] and len(out["attempts"]) == 3
     timed = [e for e in out["partial"] if "ms_per_step" in e]
     assert sorted(e["attempt"] for e in timed) == [0, 1, 2] and all(e["ms_per_step"] > 0 for e in timed)
     assert {e["calibration"] for e in timed} == {"allgather/2", "ipc_kernel/2"}      # rung 2 runs the library's own exchange
