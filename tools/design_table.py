@@ -28,10 +28,10 @@ def main(tag):
         walk = {"wave per segment": "wave", "lane group per segment (short rows)": "in-tile lane groups"}.get(sch.get("segment_walk"), sch.get("segment_walk", "?"))
         if walk and walk.startswith("lane group per segment (binned"):
             walk = "list-driven"
-        med_ns = (d.get("forward_launch_ns") or {}).get("median")
-        n_launch = max(1, round(d["forward_ns_per_step_from_rocprof"] / max(d["forward"][0]["avg_ns"], 1))) if med_ns else 1
         ms = d["forward_ns_per_step_from_rocprof"] / 1e6
-        med = f"{ms:.2f} / {med_ns * n_launch / 1e6:.2f}" if med_ns else f"{ms:.2f}"
+        med = f"{ms:.2f}"
+        if "frac_from_rocprof_median" in d:      # per step, scratch copy included: back out of the fraction
+            med += f" / {d['algorithmic_bytes_per_launch'] / (d['frac_from_rocprof_median'] * 8e12) * 1e3:.2f}"
         fr = f"{d['frac_from_rocprof_avg']:.3f}" + (f" / {d['frac_from_rocprof_median']:.3f}" if "frac_from_rocprof_median" in d else "")
         adj = d.get("adjoint", {}).get("frac_from_rocprof_avg")
         label = name.replace("_d", ", d = ") + (f" ({NOTE[name]})" if name in NOTE else "")
