@@ -871,7 +871,18 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()        # the other ranks wait here while rank 0 times the CPU legs
+        # The other ranks wait here while rank 0 times the CPU legs (tens of seconds) -- on the process group's STORE, not in a
+        # collective: a barrier would sit under the watchdog's collective time-out, and a slow host must not turn the CPU
+        # baseline of rank 0 into an abort of its peers after the measurement is done.
+        try:
+            import datetime
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set("h2gcn_bench/line_printed", "1")
+            else:
+                store.wait(["h2gcn_bench/line_printed"], datetime.timedelta(seconds=1800))
+        except Exception:  # noqa: BLE001 -- store API unavailable: the collective form
+            dist.barrier()
         dist.destroy_process_group()
 
 

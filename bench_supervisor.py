@@ -225,7 +225,14 @@ def supervise(argv, rank: int, world: int) -> int:
     n_attempts = max(1, min(MAX_RUNGS, int(os.environ.get("H2GCN_BENCH_MAX_ATTEMPTS", str(MAX_RUNGS)))))
     total_budget = float(os.environ.get("H2GCN_BENCH_TOTAL_BUDGET_S", "1500"))      # all rungs together
     t_start = time.monotonic()
-    store = _Store(rank, world, timeout_s=max(60.0, budget0))
+    try:
+        store = _Store(rank, world, timeout_s=max(60.0, budget0))
+    except Exception as e:  # noqa: BLE001 -- no key-value store to coordinate through: run the rank unsupervised rather than not at all
+        print(json.dumps({"supervisor": f"rank {rank}: no store on {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} "
+                                        f"({type(e).__name__}: {e}); running the rank without supervision"}), file=sys.stderr, flush=True)
+        env = dict(os.environ, H2GCN_BENCH_WORKER="1")
+        cmd0 = [sys.executable, str(Path(__file__).resolve().parent / "bench.py")] + list(argv)
+        os.execve(cmd0[0], cmd0, env)
     tmp = Path(tempfile.mkdtemp(prefix=f"h2gcn_bench_r{rank}_", dir="/tmp"))
     worker_cmd = os.environ.get("H2GCN_BENCH_WORKER_CMD")     # test hook: a JSON list that replaces `python bench.py <argv>`
     cmd = json.loads(worker_cmd) if worker_cmd else [sys.executable, str(Path(__file__).resolve().parent / "bench.py")] + list(argv)
