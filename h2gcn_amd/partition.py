@@ -81,20 +81,32 @@ def summarize_rccl_log(directory: Optional[str] = None, pid: Optional[int] = Non
     body = [re.sub(r"^.*?NCCL (INFO|WARN) ", lambda m: "WARN " if m.group(1) == "WARN" else "", ln).strip() for ln in text.splitlines()]
     out, seen = [], set()
 
-    def add(s):
+    def add(s, key=None):
         s = s[:240]
-        if s and s not in seen and len(out) < max_lines:
-            seen.add(s)
+        key = key or s
+        if s and key not in seen and len(out) < max_lines:
+            seen.add(key)
             out.append(s)
 
-    for pat in (r"(RCCL|NCCL) version", r"nranks \d+.*(Init COMPLETE|init)", r"\d+ coll channels"):
+    def first(pat):
         for ln in body:
             if re.search(pat, ln):
                 add(ln)
-                break
+                return
+
+    first(r"(RCCL|NCCL) version")
+    first(r"nranks \d+.*Init COMPLETE")
+    first(r"\d+ coll channels")
     chans = {int(m.group(1)) for ln in body for m in [re.match(r"Channel \d+/(\d+)\s*:", ln)] if m}
     if chans:
         add(f"ring channels: {max(chans)}")
+    # the search patterns of the topology graph: "Pattern 4, crossNic 0, nChannels 64, bw 48.0/48.0, type LOC/PIX, ..." -- ring vs
+    # tree vs direct and the link type (XGMI / PIX / ...) they were found on
+    n_pat = 0
+    for ln in body:
+        if re.match(r"Pattern \d+, crossNic", ln) and n_pat < 3 and ln[:240] not in seen:
+            add(ln)
+            n_pat += 1
     via = {}
     for ln in body:
         m = re.search(r"\bvia (\S+)", ln)
@@ -102,16 +114,19 @@ def summarize_rccl_log(directory: Optional[str] = None, pid: Optional[int] = Non
             via[m.group(1)] = via.get(m.group(1), 0) + 1
     if via:
         add("connections by transport: " + ", ".join(f"{k} x{v}" for k, v in sorted(via.items())))
-    for ln in body:
-        if ln.startswith("WARN"):
-            add(ln)
+    n_pick = 0
     for ln in body:   # e.g. "AllGather: 39321600 Bytes -> Algo 1 proto 2 time ..." (TUNING): the distinct picks
         m = re.search(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)", ln)
-        if m:
+        if m and n_pick < 3:
+            before = len(out)
             add(f"{m.group(1)} {m.group(2)} B -> algo {m.group(3)} (0 tree, 1 ring, ...) proto {m.group(4)} (0 LL, 1 LL128, 2 simple)")
+            n_pick += len(out) - before
     for ln in body:
         if re.search(r"^(Ring|Trees?) ", ln) or "Connected all" in ln:
             add(ln)
+    for ln in body:   # warnings last, one per kind (the numbers in them vary: "Could not read node # 7")
+        if ln.startswith("WARN"):
+            add(ln, key=re.sub(r"\d+", "N", ln))
     if not out:   # a log that matches none of the patterns: its first lines are still better than nothing
         for ln in body[:max_lines]:
             add(ln)

@@ -75,3 +75,27 @@ def test_rccl_log_summary(tmp_path, monkeypatch):
     assert text.count("AllGather") == 2 and "algo 1" in text             # distinct picks only
     for k in ("NCCL_DEBUG", "NCCL_DEBUG_SUBSYS", "NCCL_DEBUG_FILE"):
         monkeypatch.delenv(k, raising=False)
+
+
+def test_rccl_log_summary_on_the_format_rccl_2_26_writes(tmp_path):
+    """Lines as RCCL 2.26.6 of this image writes them (world size 1 on the GPU box): the topology search pattern is kept, the
+    per-node warnings collapse into one entry per kind, nothing else crowds the ten slots."""
+    import os
+    import socket
+
+    from h2gcn_amd.partition import summarize_rccl_log
+
+    log = "\n".join(
+        ["runc:171:171 [0] NCCL INFO RCCL version : 2.26.6-HEAD:64f48b6"]
+        + [f"[2026-09-28 23:54:08] runc:171:241 [0] /long/path/alt_rsmi.cc:675 NCCL WARN Could not read node # {i}" for i in range(3, 40)]
+        + ['[2026-09-28 23:54:05] runc:171:171 [0] /long/path/init.cc:161 NCCL WARN Missing "iommu=pt" from kernel command line',
+           "runc:171:241 [0] NCCL INFO === System : maxBw 5000.0 totalBw 5000.0 ===",
+           "runc:171:241 [0] NCCL INFO Pattern 4, crossNic 0, nChannels 64, bw 48.000000/48.000000, type LOC/PIX, sameChannels 1",
+           "runc:171:241 [0] NCCL INFO Pattern 1, crossNic 0, nChannels 64, bw 48.000000/48.000000, type LOC/PIX, sameChannels 1",
+           "runc:171:241 [0] NCCL INFO 128 coll channels, 128 collnet channels, 0 nvls channels, 64 p2p channels, 128 p2p channels per peer",
+           "runc:171:241 [0] NCCL INFO ncclCommInitRankConfig_impl comm 0x56 rank 0 nranks 1 cudaDev 0 nvmlDev 0 busId d9000 commId 0x3a - Init COMPLETE"])
+    (tmp_path / f"rccl.{socket.gethostname()}.{os.getpid()}").write_text(log)
+    got = summarize_rccl_log(str(tmp_path))
+    assert len(got) <= 10 and got[0].startswith("RCCL version") and "Init COMPLETE" in got[1] and "coll channels" in got[2]
+    assert sum("Pattern" in g for g in got) == 2
+    assert sum("Could not read node" in g for g in got) == 1 and sum("iommu" in g for g in got) == 1
