@@ -471,9 +471,9 @@ def main():
         if a.dry_exchange:
             os.environ.setdefault("NCCL_DEBUG", "INFO")   # RCCL prints the algorithm / protocol / channels it picks
     if not torch.cuda.is_available():
-        fail_line(a, "bench.py needs a GPU: h2gcn_amd has no CPU fallback", rank)
+        fail_line(a, "bench.py needs a GPU: h2gcn_amd has no CPU fallback", rank, code=USAGE_ERROR)
     if os.environ.get("H2GCN_SHARE_GPU") != "1" and local_rank >= torch.cuda.device_count():
-        fail_line(a, f"rank {rank} has LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", 0)
+        fail_line(a, f"rank {rank} has LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", 0, code=USAGE_ERROR)
     if os.environ.get("H2GCN_SHARE_GPU") == "1":  # test mode: several ranks on one GPU (RCCL refuses that -> gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)

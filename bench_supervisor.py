@@ -387,10 +387,11 @@ def supervise(argv, rank: int, world: int) -> int:
         history.append(entry)
         print(json.dumps({"supervisor": f"attempt {k} ({name}) failed", "ranks": entry["ranks"], "first_failure": entry["first_failure"]}),
               file=sys.stderr, flush=True)
-        # exit code 64 on every rank = the command line itself is wrong (bench.py's usage errors): no schedule will fix that
+        # exit code 64 on any rank = the command line / the node cannot run this at all (bench.py's usage errors, fewer GPUs than
+        # ranks): no schedule will fix that
         nxt = None
         out_of_time = total_budget - (time.monotonic() - t_start) < 45.0
-        if k < n_attempts - 1 and not out_of_time and not all(v == USAGE_ERROR for v in rcs.values()):
+        if k < n_attempts - 1 and not out_of_time and not any(v == USAGE_ERROR for v in rcs.values()):
             nxt = next_rung(history)
         if nxt is not None:
             store.set(f"a{k + 1}/rung", json.dumps(nxt))
