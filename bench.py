@@ -489,6 +489,12 @@ def main():
             # takes it from there.  (TORCH_NCCL_BLOCKING_WAIT would turn the time-out into a Python exception, but it also
             # makes every collective block the launching thread, which serialises the exchange/SpMM pipeline: not used.)
             os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            # ... and promptly: by default the watchdog spends two more minutes collecting a flight-recorder dump between the
+            # time-out and the abort (measured: timeout + 120 s); nobody reads that dump here
+            os.environ.setdefault("TORCH_NCCL_DUMP_ON_TIMEOUT", "0")
+            os.environ.setdefault("TORCH_NCCL_WAIT_TIMEOUT_DUMP_MILSEC", "2000")
+            os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "0")
+            os.environ.setdefault("TORCH_NCCL_HEARTBEAT_TIMEOUT_SEC", str(int(timeout_s) + 60))   # a watchdog that hangs itself
             # what RCCL chose (channels, transports, algorithm/protocol) goes to a file per process, summarised into the line
             import tempfile
             rccl_log_dir = os.environ.get("H2GCN_BENCH_SCRATCH") or tempfile.mkdtemp(prefix="h2gcn_rccl_", dir="/tmp")

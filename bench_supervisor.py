@@ -385,8 +385,8 @@ def supervise(argv, rank: int, world: int) -> int:
         if line is not None and line.get("error"):
             entry["error_line"] = line["error"]
         history.append(entry)
-        print(json.dumps({"supervisor": f"attempt {k} ({name}) failed", "ranks": entry["ranks"], "first_failure": entry["first_failure"]}),
-              file=sys.stderr, flush=True)
+        print(json.dumps({"supervisor": f"attempt {k} ({name}) failed after {time.monotonic() - t0:.0f} s", "ranks": entry["ranks"],
+                          "first_failure": entry["first_failure"]}), file=sys.stderr, flush=True)
         # exit code 64 on any rank = the command line / the node cannot run this at all (bench.py's usage errors, fewer GPUs than
         # ranks): no schedule will fix that
         nxt = None

@@ -34,6 +34,12 @@ def init_rccl_process_group(device: torch.device, timeout_s: Optional[float] = N
     that a rank that failed leaves its peers with an error instead of a hang."""
     import datetime
 
+    if os.environ.get("H2GCN_SHARE_GPU") == "1" and "NCCL_HOSTID" not in os.environ:
+        # Test mode (several ranks on ONE GPU): RCCL refuses two ranks with the same (host hash, PCI bus id) -- "Duplicate GPU
+        # detected".  A host id of its own per rank makes the ranks look like different hosts: RCCL then connects them through
+        # its NET/Socket transport, and ProcessGroupNCCL, its streams, its watchdog and every collective run for real with
+        # world > 1 on a one-GPU box.  (The transport is not xGMI; everything above the transport is what an 8-GPU node runs.)
+        os.environ["NCCL_HOSTID"] = f"h2gcn-shared-gpu-rank-{os.environ.get('RANK', '0')}"
     kw = {} if timeout_s is None else {"timeout": datetime.timedelta(seconds=float(timeout_s))}
     try:
         opts = dist.ProcessGroupNCCL.Options()
@@ -114,13 +120,16 @@ def summarize_rccl_log(directory: Optional[str] = None, pid: Optional[int] = Non
             via[m.group(1)] = via.get(m.group(1), 0) + 1
     if via:
         add("connections by transport: " + ", ".join(f"{k} x{v}" for k, v in sorted(via.items())))
-    n_pick = 0
-    for ln in body:   # e.g. "AllGather: 39321600 Bytes -> Algo 1 proto 2 time ..." (TUNING): the distinct picks
-        m = re.search(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)", ln)
-        if m and n_pick < 3:
-            before = len(out)
-            add(f"{m.group(1)} {m.group(2)} B -> algo {m.group(3)} (0 tree, 1 ring, ...) proto {m.group(4)} (0 LL, 1 LL128, 2 simple)")
-            n_pick += len(out) - before
+    # TUNING: "AllGather: 39321600 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..15}" (RCCL 2.26; older builds print
+    # numbers).  One pick per collective -- the one for its LARGEST message, the regime the exchange lives in -- AllGather first
+    picks = {}
+    for ln in body:
+        m = re.search(r"(\w+): (\d+) Bytes -> Algo (\S+) proto (\S+)(?: channel\{Lo\.\.Hi\}=\{(\d+)\.\.(\d+)\})?", ln)
+        if m and (m.group(1) not in picks or int(m.group(2)) > picks[m.group(1)][0]):
+            picks[m.group(1)] = (int(m.group(2)), m.group(3), m.group(4), m.group(5), m.group(6))
+    for name in sorted(picks, key=lambda k: (k != "AllGather", -picks[k][0]))[:3]:
+        nbytes, algo, proto, lo, hi = picks[name]
+        add(f"{name} of {nbytes} B -> algorithm {algo}, protocol {proto}" + (f", channels {lo}..{hi}" if lo is not None else ""))
     for ln in body:
         if re.search(r"^(Ring|Trees?) ", ln) or "Connected all" in ln:
             add(ln)

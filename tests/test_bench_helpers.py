@@ -46,9 +46,10 @@ host:123:140 [0] NCCL INFO Channel 00/0 : 0[0] -> 2[2] via SHM/direct/direct
 host:123:140 [0] NCCL INFO Connected all rings
 host:123:140 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels, 2 p2p channels per peer
 host:123:140 [0] NCCL INFO comm 0x55 rank 0 nranks 8 cudaDev 0 nvmlDev 0 busId 5000 commId 0xabc - Init COMPLETE
-host:123:140 [0] NCCL INFO AllGather: 39321600 Bytes -> Algo 1 proto 2 time 310.0
-host:123:140 [0] NCCL INFO AllGather: 39321600 Bytes -> Algo 1 proto 2 time 310.0
-host:123:140 [0] NCCL INFO AllGather: 19660800 Bytes -> Algo 1 proto 2 time 160.0
+host:123:140 [0] NCCL INFO AllGather: 39321600 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..15}
+host:123:140 [0] NCCL INFO AllGather: 39321600 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..15}
+host:123:140 [0] NCCL INFO AllGather: 19660800 Bytes -> Algo RING proto LL128 channel{Lo..Hi}={0..7}
+host:123:140 [0] NCCL INFO AllReduce: 16 Bytes -> Algo TREE proto LL channel{Lo..Hi}={0..0}
 """
 
 
@@ -72,7 +73,8 @@ def test_rccl_log_summary(tmp_path, monkeypatch):
     text = "\n".join(got)
     assert "version 2.22.3" in text and "nranks 8" in text and "ring channels: 16" in text
     assert "P2P/IPC x2" in text and "SHM/direct/direct x1" in text
-    assert text.count("AllGather") == 2 and "algo 1" in text             # distinct picks only
+    assert "AllGather of 39321600 B -> algorithm RING, protocol SIMPLE, channels 0..15" in text   # the pick for the largest message
+    assert text.count("AllGather") == 1 and "AllReduce of 16 B -> algorithm TREE, protocol LL" in text
     for k in ("NCCL_DEBUG", "NCCL_DEBUG_SUBSYS", "NCCL_DEBUG_FILE"):
         monkeypatch.delenv(k, raising=False)
 

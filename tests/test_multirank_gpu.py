@@ -1,7 +1,10 @@
-"""GPU suite: the N > 1 orchestration on REAL kernels, streams and events with two processes that share the one
-GPU of the test box.  RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the collective goes
-through gloo here; everything else -- shard generation, staging, side-stream exchange, event hand-off, the HIP
-launches, reduce-scatter of the adjoint -- is the code path the 8-GPU run uses."""
+"""GPU suite: the N > 1 orchestration on REAL kernels, streams and events with several processes that share the one
+GPU of the test box -- shard generation, staging, side-stream exchange, event hand-off, the HIP launches, reduce-scatter
+of the adjoint: the code path the 8-GPU run uses.  Collectives: gloo (rounds 2-4), and since round 5 RCCL ITSELF with
+2-4 ranks: RCCL refuses two ranks with the same (host, PCI bus id) ("Duplicate GPU detected"), but a NCCL_HOSTID of its own
+per rank (partition.init_rccl_process_group does that in H2GCN_SHARE_GPU mode) makes the ranks look like different hosts,
+and RCCL connects them through its NET/Socket transport.  Not xGMI -- but ProcessGroupNCCL, its streams and watchdog,
+ncclAllGather / grouped ncclSend+ncclRecv / ncclReduceScatter and the all_gather_object bootstrap run for real."""
 import json
 import os
 import socket
@@ -25,7 +28,12 @@ from h2gcn_amd.partition import PipelinedHopAggregation, block_bounds, sharded_h
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
-dist.init_process_group("gloo")
+if os.environ.get("BACKEND", "gloo") == "nccl":
+    from h2gcn_amd.partition import init_rccl_process_group
+    os.environ["H2GCN_SHARE_GPU"] = "1"            # ranks on one GPU: a host id per rank (see the module docstring)
+    init_rccl_process_group(dev, 120.0)
+else:
+    dist.init_process_group("gloo")
 n, d, chunks = 30000, 128, int(os.environ["CHUNKS"])
 r0, r1 = block_bounds(n, world, rank)
 degs = [synth.synth_degrees(n, 40 * n, s, n) for s in (1, 2)]
@@ -154,9 +162,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("exchange,chunks", [("allgather", 1), ("allgather", 2), ("ipc_engine", 1), ("ipc_engine", 2),
-                                             ("ipc_kernel", 1), ("ipc_kernel", 2)])
-def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, exchange, chunks):
+@pytest.mark.parametrize("exchange,chunks,backend", [("allgather", 1, "gloo"), ("allgather", 2, "gloo"), ("ipc_engine", 1, "gloo"),
+                                                     ("ipc_engine", 2, "gloo"), ("ipc_kernel", 1, "gloo"), ("ipc_kernel", 2, "gloo"),
+                                                     # ... and over RCCL itself: ncclAllGather + ncclReduceScatter on the side stream,
+                                                     # grouped ncclSend/ncclRecv, the IPC bootstrap through all_gather_object
+                                                     ("allgather", 2, "nccl"), ("p2p", 2, "nccl"), ("ipc_kernel", 2, "nccl")])
+def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, exchange, chunks, backend):
     from h2gcn_amd import HopPlan, synth
     from h2gcn_amd.partition import PipelinedHopAggregation
 
@@ -164,7 +175,8 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, exchange, chunks):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OUT_DIR=str(tmp_path), CHUNKS=str(chunks), EXCHANGE=exchange, H2GCN_ROOT=str(ROOT))
+                   OUT_DIR=str(tmp_path), CHUNKS=str(chunks), EXCHANGE=exchange, H2GCN_ROOT=str(ROOT), BACKEND=backend)
+        env.pop("NCCL_HOSTID", None)
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
@@ -197,12 +209,13 @@ if int(os.environ.get("RANK", "0")) == 0:
 '''
 
 
-@pytest.mark.parametrize("network,exchange", [
-    ("M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", "allgather"),        # H2GCN-2: concat-free sharded propagation
-    ("M64-R-T1-G0-V-T2-G0_1-V-C1_2-D0.0-MO", "allgather"),     # hop filters on the shards
-    ("M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", "ipc_engine"),       # the same with the library's own IPC all-gather
-])
-def test_row_partitioned_training_matches_single_process(tmp_path, network, exchange):
+@pytest.mark.parametrize("network,exchange,backend", [
+    ("M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", "allgather", "gloo"),        # H2GCN-2: concat-free sharded propagation
+    ("M64-R-T1-G0-V-T2-G0_1-V-C1_2-D0.0-MO", "allgather", "gloo"),     # hop filters on the shards
+    ("M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", "ipc_engine", "gloo"),       # the same with the library's own IPC all-gather
+    ("M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", "allgather", "nccl"),        # ... and over RCCL: ncclAllGather forward, ncclReduceScatter
+])                                                                     #     backward, ncclAllReduce of dW, broadcast of the kernels
+def test_row_partitioned_training_matches_single_process(tmp_path, network, exchange, backend):
     """`run_experiments` under torch.distributed (2 ranks, rows of features / hop matrices / labels partitioned,
     dense kernels replicated, all-gather forward, reduce-scatter + gradient all-reduce backward) follows the
     single-process training trajectory.  Dropout is disabled so both runs are deterministic."""
@@ -221,7 +234,8 @@ def test_row_partitioned_training_matches_single_process(tmp_path, network, exch
             env = dict(os.environ, H2GCN_ROOT=str(ROOT), DATA_DIR=str(data_dir), OUT_FILE=str(out_file), NETWORK=network, H2GCN_EXCHANGE=exchange)
             if world > 1:
                 env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                           MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1")
+                           MASTER_PORT=str(port), H2GCN_DIST_BACKEND=backend, H2GCN_SHARE_GPU="1")
+                env.pop("NCCL_HOSTID", None)
             else:
                 env.pop("WORLD_SIZE", None)
             procs.append(subprocess.Popen([sys.executable, "-c", TRAIN_WORKER], env=env, stdout=subprocess.PIPE,
@@ -623,7 +637,7 @@ def _run_supervised(world, extra, env_extra, timeout=1500):
     port = _free_port()
     procs = []
     for rank in range(world):
-        env = {k: v for k, v in os.environ.items() if k != "H2GCN_BENCH_WORKER"}
+        env = {k: v for k, v in os.environ.items() if k not in ("H2GCN_BENCH_WORKER", "NCCL_HOSTID")}
         env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1", H2GCN_BENCH_SKIP_DRY="1",
                    H2GCN_BENCH_EXCHANGES="allgather,ipc_kernel", H2GCN_BENCH_PEER_FAILURE_GRACE_S="2")
@@ -693,6 +707,55 @@ def test_bench_survives_a_rank_that_hangs_inside_exchange_only(tmp_path):
     assert out["value"] > 0 and out["config"]["checksum_matches_n1"] is True
     first = out["config"]["diagnostics"]["first_attempt"]
     assert "budget" in first["first_failure"] and len([e for e in first["calibration"] if "ms_per_step" in e]) >= 2
+
+
+def test_rccl_itself_with_three_ranks_on_one_gpu():
+    """RCCL with world size 3 on the box's one GPU (a NCCL_HOSTID per rank; NET/Socket transport): all_gather_into_tensor,
+    all_reduce, the grouped isend/irecv all-to-all form, reduce_scatter_tensor and barrier deliver the right bytes."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NCCL_HOSTID")}
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "rccl_shared_gpu_probe.py"), "3"], env=env, capture_output=True, text=True, timeout=900)
+    ok = [ln for ln in r.stdout.splitlines() if ln.startswith("rank ") and "all_gather True all_reduce True p2p True reduce_scatter True" in ln]
+    assert r.returncode == 0 and len(ok) == 3, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_bench_two_ranks_over_rccl(tmp_path):
+    """bench.py's N > 1 branch under the REAL nccl backend with 2 ranks (sharing the GPU, see the module docstring): the
+    first-contact table, the calibration over all four exchange forms -- one ncclAllGather per chunk on the high-priority side
+    stream, grouped ncclSend/ncclRecv, both IPC forms bootstrapped through all_gather_object over RCCL -- each candidate
+    checked against the regenerated embedding, the timed steps, the bits of the single-GPU result, and what RCCL chose
+    (config.diagnostics.rccl, from its per-process debug FILE: nothing of it on stdout)."""
+    out = _run_bench(2, ["--shape", "arxiv", "--steps", "3", "--warmup", "1", "--chunks", "2"], tmp_path,
+                     env_extra={"H2GCN_DIST_BACKEND": "nccl", "H2GCN_BENCH_SKIP_DRY": "0"})
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["dist_backend"] == "nccl"
+    assert out["config"]["checksum_matches_n1"] is True
+    diag = out["config"]["diagnostics"]
+    assert set(diag["calibration_ms_per_step"]) == {"allgather/2", "ipc_kernel/2", "ipc_engine/2", "p2p/2"}, diag["rejected"]
+    assert list(diag["calibration_ms_per_step"])[:2] == ["allgather/2", "ipc_kernel/2"]            # safest first
+    fc = diag["first_contact_dry_exchange"]["dry_exchange"]
+    assert {"allgather/2", "p2p/2", "ipc_kernel/2"} <= set(fc), diag["first_contact_dry_exchange"]
+    rccl = diag["rccl"]
+    assert 0 < len(rccl) <= 10 and any("nranks 2" in ln for ln in rccl) and any("version" in ln for ln in rccl), rccl
+    _keep("bench_shared_gpu_arxiv_n2_rccl.json", out)
+
+
+def test_bench_survives_a_real_rccl_watchdog_abort(tmp_path):
+    """The failure the supervisor exists for, for real: rank 1 stops responding, rank 0 sits in an RCCL collective, the
+    ProcessGroupNCCL watchdog gives up after H2GCN_DIST_TIMEOUT_S and takes rank 0's process down -- not a Python exception.
+    One line on stdout all the same, measured by the relaunch, with the calibration the first attempt had completed."""
+    lines, err, rcs = _run_supervised(2, ["--chunks", "2"], {"H2GCN_DIST_BACKEND": "nccl", "H2GCN_BENCH_HANG_RANK": "1",
+                                                             "H2GCN_BENCH_FAIL_STAGE": "exchange_only", "H2GCN_DIST_TIMEOUT_S": "15",
+                                                             "H2GCN_BENCH_ATTEMPT_BUDGET_S": "240"})
+    if os.environ.get("H2GCN_TEST_ARTIFACTS"):
+        Path(os.environ["H2GCN_TEST_ARTIFACTS"]).mkdir(parents=True, exist_ok=True)
+        (Path(os.environ["H2GCN_TEST_ARTIFACTS"]) / "bench_shared_gpu_rccl_watchdog_abort_n2.stderr.txt").write_text(err)
+    assert len(lines) == 1 and rcs == [0, 0], (lines, err[-3000:])
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["config"]["checksum_matches_n1"] is True and out["config"]["dist_backend"] == "nccl"
+    first = out["config"]["diagnostics"]["first_attempt"]
+    assert first["ranks"]["0"].startswith("killed by SIG"), first                  # the watchdog's abort, not an exit code
+    assert "budget" not in (first["first_failure"] or ""), first                   # ... long before the attempt's budget
+    assert len([e for e in first["calibration"] if "ms_per_step" in e]) == 2
+    _keep("bench_shared_gpu_rccl_watchdog_abort_n2.json", out)
 
 
 def test_bench_more_ranks_than_gpus_is_one_error_line():
