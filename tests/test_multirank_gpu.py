@@ -605,13 +605,19 @@ def test_bench_eight_ranks_on_one_gpu(tmp_path):
     assert one["config"]["y_checksum"] == out["config"]["y_checksum"]
 
 
-def test_bench_plain_launch_spawns_its_own_ranks(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_bench_plain_launch_spawns_its_own_ranks(tmp_path, backend):
     """`python bench.py --gpus 2 ...` with NO torch.distributed.run environment (the shape of the driver's N = 1 command):
     bench.py re-executes itself under torch.distributed.run, rank 0 prints the one line, and that line carries what the
     single-GPU line carries -- roofline (rank 0's and every rank's), cpu_baseline (rank 0's row block, after the timed
     region), the first-contact exchange table -- and `checksum_matches_n1`-style evidence: the checksum of the 1-rank run."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(H2GCN_SHARE_GPU="1", H2GCN_DIST_BACKEND="gloo", H2GCN_BENCH_EXCHANGES="allgather,ipc_kernel")
+    env.update(H2GCN_SHARE_GPU="1", H2GCN_BENCH_EXCHANGES="allgather,ipc_kernel")
+    env.pop("NCCL_HOSTID", None)
+    if backend == "gloo":
+        env["H2GCN_DIST_BACKEND"] = "gloo"
+    else:
+        env.pop("H2GCN_DIST_BACKEND", None)     # the DEFAULT backend: RCCL -- the driver's command, short of a second device
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--shape", "arxiv", "--steps", "2", "--warmup", "1",
                         "--chunks", "2", "--cpu-seconds", "0.5", "--no-probe", "--no-traffic", "--no-hbm-leg"], env=env,
                        capture_output=True, text=True, timeout=1500)
@@ -619,7 +625,8 @@ def test_bench_plain_launch_spawns_its_own_ranks(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["dist_backend"] == backend
+    assert (backend == "gloo") == ("rccl" not in out["config"]["diagnostics"])
     assert len(out["roofline"]["per_rank"]) == 2 and all(q["frac"] > 0 for q in out["roofline"]["per_rank"])
     assert out["cpu_baseline"]["value"] > 0 and "row block" in out["cpu_baseline"]["sample"]
     fc = out["config"]["diagnostics"]["first_contact_dry_exchange"]
@@ -628,7 +635,7 @@ def test_bench_plain_launch_spawns_its_own_ranks(tmp_path):
     assert out["config"]["checksum_matches_n1"] is True      # against the constant of the single-GPU line embedded in bench.py
     one = _run_bench(1, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--no-adjoint"], tmp_path)
     assert one["config"]["y_checksum"] == out["config"]["y_checksum"]
-    _keep("bench_plain_launch_arxiv_n2.json", out)
+    _keep(f"bench_plain_launch_arxiv_n2_{backend}.json", out)
 
 
 def _run_supervised(world, extra, env_extra, timeout=1500):
