@@ -529,10 +529,14 @@ def test_bench_multi_rank_branch_runs_and_matches_one_rank(tmp_path, world):
     JSON line) on the arxiv shape, N ranks sharing the box's GPU; the N-rank result -- whatever chunking the calibration
     picked -- has the same bits as the default 1-rank line (one launch) AND as 1-rank runs with other chunkings / slice
     widths (order-independent checksum of Y): the canonical summation tree, SURVEY.md 8(e) "Determinism"."""
-    # (N = 4: the gloo stand-in for the grouped send/recv exchange takes ~3 s per step on a shared GPU -- left to N = 2)
-    extra_env = {"H2GCN_BENCH_EXCHANGES": "allgather,ipc_engine,ipc_kernel"} if world >= 3 else None   # (170 000 rows / 3: a short last block)
+    # N = 2 and 4: under RCCL itself (all four exchange forms x four chunkings = the full 16-candidate sweep of the 8-GPU run);
+    # N = 3 (170 000 rows / 3: a short last block) over gloo, without its slow stand-in for the grouped send/recv form
+    extra_env = {"H2GCN_BENCH_EXCHANGES": "allgather,ipc_engine,ipc_kernel"} if world == 3 else {"H2GCN_DIST_BACKEND": "nccl"}
     out = _run_bench(world, ["--shape", "arxiv", "--steps", "3", "--warmup", "1"], tmp_path, env_extra=extra_env)
     assert out["n_gpus"] == world and out["value"] > 0 and out["roofline"]["kernel_ms_max_over_ranks"] > 0
+    assert out["config"]["dist_backend"] == ("gloo" if world == 3 else "nccl")
+    if world != 3:
+        assert len(diag_cal := out["config"]["diagnostics"]["calibration_ms_per_step"]) == 16, (diag_cal, out["config"]["diagnostics"]["rejected"])
     diag = out["config"]["diagnostics"]
     cal = diag["calibration_ms_per_step"]
     assert cal and all(v > 0 for v in cal.values())
@@ -590,17 +594,22 @@ def test_bench_survives_an_exchange_that_fails_on_one_rank(tmp_path):
     assert all("IPC exchange unavailable" in v or "another rank" in v for v in diag["rejected"].values()), diag["rejected"]
 
 
-def test_bench_eight_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_bench_eight_ranks_on_one_gpu(tmp_path, backend):
     """The target rank count (configs[4]: 8 ranks) end to end on the arxiv shape, eight processes sharing the box's GPU:
     block bounds, 7 peers per rank in the IPC pulls, calibration agreement across 8 ranks, the checksum against one rank.
     (Copy-engine pulls are left out: 8 x 7 spin-wait kernels time-slicing one device take minutes, see
     profiles/r02_ipc_exchange_stress.txt.)"""
+    # backend "nccl": RCCL itself with 8 ranks (a NCCL_HOSTID per rank, see the module docstring), grouped send/recv included
+    exchanges = "allgather,ipc_kernel" if backend == "gloo" else "allgather,ipc_kernel,p2p"
     out = _run_bench(8, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--chunks", "2", "--no-adjoint"], tmp_path,
-                     env_extra={"H2GCN_BENCH_EXCHANGES": "allgather,ipc_kernel"})
-    assert out["n_gpus"] == 8 and out["value"] > 0
+                     env_extra={"H2GCN_BENCH_EXCHANGES": exchanges, "H2GCN_DIST_BACKEND": backend})
+    assert out["n_gpus"] == 8 and out["value"] > 0 and out["config"]["dist_backend"] == backend
     cal = out["config"]["diagnostics"]["calibration_ms_per_step"]
-    assert set(cal) == {"allgather/2", "ipc_kernel/2"}, (cal, out["config"]["diagnostics"]["rejected"])
-    _keep("bench_shared_gpu_arxiv_n8.json", out)
+    assert set(cal) == {f"{ex}/2" for ex in exchanges.split(",")}, (cal, out["config"]["diagnostics"]["rejected"])
+    if backend == "nccl":
+        assert any("nranks 8" in ln for ln in out["config"]["diagnostics"]["rccl"]), out["config"]["diagnostics"]["rccl"]
+    _keep(f"bench_shared_gpu_arxiv_n8_{backend}.json", out)
     one = _run_bench(1, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--no-adjoint"], tmp_path)
     assert one["config"]["y_checksum"] == out["config"]["y_checksum"]
 
