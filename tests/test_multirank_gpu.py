@@ -351,7 +351,9 @@ def test_row_partitioned_training_replays_as_hipgraph(tmp_path):
     _export_fixture(load_planetoid_golden("cora"), data_dir, "ind.cora")
     network = "M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO"
     results, logs = {}, {}
-    for tag, world, extra in (("one", 1, "--no_hipgraph"), ("eager", 2, "--no_hipgraph"), ("replay", 2, "")):
+    # "replay_rccl": the same replayed run bootstrapped over RCCL (process group, broadcast of the kernels, all_gather_object
+    # of the IPC handles, the barriers around the captures) instead of gloo
+    for tag, world, extra in (("one", 1, "--no_hipgraph"), ("eager", 2, "--no_hipgraph"), ("replay", 2, ""), ("replay_rccl", 2, "")):
         port = _free_port()
         procs = []
         out_file = tmp_path / f"stats_{tag}.json"
@@ -360,7 +362,8 @@ def test_row_partitioned_training_replays_as_hipgraph(tmp_path):
                        H2GCN_EXCHANGE="ipc_kernel", EPOCHS="30", EXTRA=extra, PROP_DUMP=str(tmp_path / f"prop_{tag}"))
             if world > 1:
                 env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                           MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1")
+                           MASTER_PORT=str(port), H2GCN_DIST_BACKEND="nccl" if tag.endswith("_rccl") else "gloo", H2GCN_SHARE_GPU="1")
+                env.pop("NCCL_HOSTID", None)
             else:
                 env.pop("WORLD_SIZE", None)
             procs.append(subprocess.Popen([sys.executable, "-c", TRAIN_WORKER_TIMED], env=env, stdout=subprocess.PIPE,
@@ -368,14 +371,15 @@ def test_row_partitioned_training_replays_as_hipgraph(tmp_path):
         outs = [p.communicate(timeout=900)[0].decode() for p in procs]
         assert all(p.returncode == 0 for p in procs), "\n".join(outs)
         results[tag], logs[tag] = json.loads(out_file.read_text()), outs
-    assert not any("capture unavailable" in o for o in logs["replay"]), logs["replay"][0][-2000:]
+    for tag in ("replay", "replay_rccl"):
+        assert not any("capture unavailable" in o for o in logs[tag]), logs[tag][0][-2000:]
     # BIT equality: the replayed graph contains the very kernels of the eager step (h2gcn_adam_keras_f32 is one launch in
     # both modes, every reduction has a fixed order), so 30 epochs end in identical statistics -- one deterministic update
     # per step, as in the reference (h2gcn/models/H2GCN.py:66-74)
     for k in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_accuracy"):
-        assert results["eager"][k] == results["replay"][k], (k, results["eager"][k], results["replay"][k])
+        assert results["eager"][k] == results["replay"][k] == results["replay_rccl"][k], (k, results["eager"][k], results["replay"][k], results["replay_rccl"][k])
     # the propagation itself (exchange + SpMM) is BIT-equal between 1 and 2 ranks, eager or about to be captured ...
-    for tag in ("eager", "replay"):
+    for tag in ("eager", "replay", "replay_rccl"):
         _assert_propagation_bit_equal(tmp_path / "prop_one", tmp_path / f"prop_{tag}", 2)
     # ... the 2e-3 on the losses after 30 epochs comes from the rank-order all-reduce of the dense kernels' gradients alone
     for k in ("train_loss", "val_loss", "test_loss"):
