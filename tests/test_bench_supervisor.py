@@ -72,7 +72,7 @@ def _env(tmp_path, scenario, **extra):
     fake.write_text(FAKE_WORKER)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "H2GCN_BENCH_WORKER")}
     env.update(FAKE_SCENARIO=scenario, H2GCN_BENCH_WORKER_CMD=json.dumps([sys.executable, str(fake)]),
-               H2GCN_BENCH_ATTEMPT_BUDGET_S="4", H2GCN_BENCH_PEER_FAILURE_GRACE_S="0.5", H2GCN_BENCH_TEARDOWN_GRACE_S="1")
+               H2GCN_BENCH_ATTEMPT_BUDGET_S="10", H2GCN_BENCH_PEER_FAILURE_GRACE_S="0.5", H2GCN_BENCH_TEARDOWN_GRACE_S="1")
     env.update(extra)
     return env
 
