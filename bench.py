@@ -239,12 +239,12 @@ def hbm_resident_leg(timeout_s=600):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def dry_exchange(a, world, rank, device, backend, to_stderr=False):
+def dry_exchange(a, world, rank, device, backend, to_stderr=False, rccl_log_dir=None):
     """`--dry-exchange` (N > 1): FIRST-CONTACT check of every exchange form on this node before any big allocation --
     1 MiB shards, a handful of rounds each, per-candidate GB/s of landed bytes, which candidates fail and why.  Meant to
     be the first thing run on a multi-GPU box: it exercises the RCCL high-priority stream, the grouped send/recv form
-    and the IPC handle exchange with real peers, and (NCCL_DEBUG=INFO is switched on before the process group starts)
-    makes RCCL print the algorithm / protocol / channel count it picks to stderr."""
+    and the IPC handle exchange with real peers, and the table carries what RCCL chose (channels, transports, algorithm /
+    protocol picks: condensed from its per-process debug file, `rccl`)."""
     from h2gcn_amd import HopPlan, synth
     from h2gcn_amd.partition import PipelinedHopAggregation, RowPartition
 
@@ -313,6 +313,9 @@ def dry_exchange(a, world, rank, device, backend, to_stderr=False):
     report = {"dry_exchange": table, "rejected": rejected, "n_gpus": world, "shard_bytes": per * d * 4,
               "dist_backend": backend, "GPU_MAX_HW_QUEUES": hwq,
               "note": "1 MiB shards: latency-dominated rates, a smoke test of every exchange form -- not a bandwidth figure"}
+    if backend == "nccl" and rank == 0 and rccl_log_dir:
+        from h2gcn_amd.partition import summarize_rccl_log
+        report["rccl"] = summarize_rccl_log(rccl_log_dir)
     if to_stderr:
         progress(report, rank)
     elif rank == 0:
@@ -468,13 +471,11 @@ def main():
         # the exchange pipeline drives up to world + 1 streams (main, exchange / one per peer); HIP multiplexes streams
         # onto GPU_MAX_HW_QUEUES hardware queues (default 4) -- give every stream its own, before the runtime starts
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(world + 2, 4), 12)))
-        if a.dry_exchange:
-            os.environ.setdefault("NCCL_DEBUG", "INFO")   # RCCL prints the algorithm / protocol / channels it picks
     if not torch.cuda.is_available():
         fail_line(a, "bench.py needs a GPU: h2gcn_amd has no CPU fallback", rank, code=USAGE_ERROR)
     if os.environ.get("H2GCN_SHARE_GPU") != "1" and local_rank >= torch.cuda.device_count():
         fail_line(a, f"rank {rank} has LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", 0, code=USAGE_ERROR)
-    if os.environ.get("H2GCN_SHARE_GPU") == "1":  # test mode: several ranks on one GPU (RCCL refuses that -> gloo)
+    if os.environ.get("H2GCN_SHARE_GPU") == "1":  # test mode: several ranks on one GPU (gloo, or RCCL with a host id per rank)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -510,7 +511,7 @@ def main():
     if a.dry_exchange:
         if world < 2:
             raise SystemExit("--dry-exchange needs N > 1 ranks")   # (a usage error, not a measurement: plain message)
-        dry_exchange(a, world, rank, device, backend)
+        dry_exchange(a, world, rank, device, backend, rccl_log_dir=rccl_log_dir)
         dist.destroy_process_group()
         return
     first_contact = None

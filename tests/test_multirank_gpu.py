@@ -568,6 +568,10 @@ def test_bench_dry_exchange_mode(tmp_path):
         for spec in ("1", "2"):
             row = out["dry_exchange"].get(f"{ex}/{spec}")
             assert row and row["ms_per_exchange"] > 0 and row["landed_GBps_per_rank"] > 0, (ex, spec, out["rejected"])
+    # under RCCL itself the table also says what RCCL chose (from its debug FILE; stdout stays one line)
+    out = _run_bench(2, ["--dry-exchange", "--exchange", "allgather"], tmp_path, env_extra={"H2GCN_DIST_BACKEND": "nccl"})
+    assert out["dist_backend"] == "nccl" and out["dry_exchange"]["allgather/2"]["ms_per_exchange"] > 0
+    assert any("nranks 2" in ln for ln in out["rccl"]), out["rccl"]
     # copy-engine pulls are refused when the hardware queues cannot hold one parked wait kernel per peer
     out = _run_bench(2, ["--dry-exchange", "--exchange", "ipc_engine"], tmp_path, env_extra={"GPU_MAX_HW_QUEUES": "2"})
     assert not out["dry_exchange"] and all("GPU_MAX_HW_QUEUES" in v for v in out["rejected"].values())
