@@ -238,10 +238,13 @@ def supervise(argv, rank: int, world: int) -> int:
     cmd = json.loads(worker_cmd) if worker_cmd else [sys.executable, str(Path(__file__).resolve().parent / "bench.py")] + list(argv)
     current = {"w": None}
 
+    printed = {"line": False}        # stdout carries exactly ONE line: whoever prints it sets this first
+
     def on_signal(signum, _frame):   # the launcher is taking the job down (time limit, ^C): no orphans, and still one line
         if current["w"] is not None:
             current["w"].kill(1.0)
-        if rank == 0:
+        if rank == 0 and not printed["line"]:
+            printed["line"] = True
             print(json.dumps({"metric": METRIC, "value": None, "unit": "edges/s", "n_gpus": world,
                               "error": f"supervisor received {signal.Signals(signum).name}",
                               "partial": _progress_entries(tmp / "progress.jsonl")}), flush=True)
@@ -300,7 +303,9 @@ def supervise(argv, rank: int, world: int) -> int:
                 if len(history) > 1:
                     diag["failed_attempts"] = history[1:]
             store.set(f"a{k}/verdict", "ok")
-            print(json.dumps(line_), flush=True)
+            if not printed["line"]:
+                printed["line"] = True
+                print(json.dumps(line_), flush=True)
 
         while True:
             rc = w.poll()
@@ -398,7 +403,8 @@ def supervise(argv, rank: int, world: int) -> int:
         store.set(f"a{k}/verdict", "retry" if nxt is not None else "fail")
         if nxt is None:
             break
-    if rank == 0 and final != 0:
+    if rank == 0 and final != 0 and not printed["line"]:
+        printed["line"] = True
         partial = [e for h in history for e in h.get("calibration", [])]
         print(json.dumps({"metric": METRIC, "value": None, "unit": "edges/s", "n_gpus": world,
                           "error": f"every attempt failed ({len(history)}): "
