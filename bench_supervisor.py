@@ -411,6 +411,9 @@ def supervise(argv, rank: int, world: int) -> int:
                                    + "; ".join(f"[{h['attempt']}] {h.get('error_line') or h.get('first_failure') or h.get('error') or h.get('ranks')}"
                                                for h in history),
                           "attempts": history, "partial": partial}), flush=True)
+    if os.environ.get("H2GCN_BENCH_KEEP_SCRATCH") != "1":      # worker stdout, progress records, RCCL's debug files
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
     # a store hosted by rank 0's supervisor must outlive the other supervisors' last look at it
     store.set(f"bye{rank}", 1)
     if store.hosted:
