@@ -609,7 +609,8 @@ def test_bench_eight_ranks_on_one_gpu(tmp_path, backend):
     (Copy-engine pulls are left out: 8 x 7 spin-wait kernels time-slicing one device take minutes, see
     profiles/r02_ipc_exchange_stress.txt.)"""
     # backend "nccl": RCCL itself with 8 ranks (a NCCL_HOSTID per rank, see the module docstring), grouped send/recv included
-    exchanges = "allgather,ipc_kernel" if backend == "gloo" else "allgather,ipc_kernel,p2p"
+    # (gloo: its host-staged all-gather with 8 ranks on one GPU takes most of a minute and is covered at N = 2 / 3 -- IPC form only)
+    exchanges = "ipc_kernel" if backend == "gloo" else "allgather,ipc_kernel,p2p"
     out = _run_bench(8, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--chunks", "2", "--no-adjoint"], tmp_path,
                      env_extra={"H2GCN_BENCH_EXCHANGES": exchanges, "H2GCN_DIST_BACKEND": backend})
     assert out["n_gpus"] == 8 and out["value"] > 0 and out["config"]["dist_backend"] == backend
@@ -725,7 +726,7 @@ def test_bench_survives_a_rank_that_hangs_inside_exchange_only(tmp_path):
     """A rank that stops responding (never returns from the diagnostics' exchange_only stage) instead of dying: its peers
     block in the collective; the attempt's wall-clock budget takes all of them down and the relaunch delivers the line."""
     lines, err, rcs = _run_supervised(2, ["--chunks", "2"], {"H2GCN_BENCH_HANG_RANK": "1", "H2GCN_BENCH_FAIL_STAGE": "exchange_only",
-                                                             "H2GCN_BENCH_ATTEMPT_BUDGET_S": "45", "H2GCN_DIST_TIMEOUT_S": "900"})
+                                                             "H2GCN_BENCH_ATTEMPT_BUDGET_S": "35", "H2GCN_DIST_TIMEOUT_S": "900"})
     assert len(lines) == 1 and rcs == [0, 0], (lines, err[-3000:])
     out = json.loads(lines[0])
     assert out["value"] > 0 and out["config"]["checksum_matches_n1"] is True
