@@ -265,7 +265,13 @@ def dry_exchange(a, world, rank, device, backend, to_stderr=False, rccl_log_dir=
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item() > 0)
 
-    for ex in exchange_families(a):
+    fams = exchange_families(a)
+    if to_stderr and not a.exchange:
+        # inside a measuring run the table is a quick smoke test of RCCL and of the IPC bootstrap BEFORE the big allocations: the
+        # two safest forms only.  The others (copy-engine pulls, grouped send/recv) meet the node inside the calibration, which
+        # runs safest-first -- if one of them takes the job down there, every safer candidate is already timed and on record
+        fams = [f for f in fams if EXCHANGE_ORDER.get(f, 9) < 2] or fams[:1]
+    for ex in fams:
         for spec in ([a.chunks] if a.chunks else ["1", "2"]):
             key = f"{ex}/{spec}"
             if ex == "ipc_engine" and world - 1 > hwq - 2:

@@ -757,7 +757,7 @@ def test_bench_two_ranks_over_rccl(tmp_path):
     assert set(diag["calibration_ms_per_step"]) == {"allgather/2", "ipc_kernel/2", "ipc_engine/2", "p2p/2"}, diag["rejected"]
     assert list(diag["calibration_ms_per_step"])[:2] == ["allgather/2", "ipc_kernel/2"]            # safest first
     fc = diag["first_contact_dry_exchange"]["dry_exchange"]
-    assert {"allgather/2", "p2p/2", "ipc_kernel/2"} <= set(fc), diag["first_contact_dry_exchange"]
+    assert set(fc) == {"allgather/2", "ipc_kernel/2"}, diag["first_contact_dry_exchange"]     # the two safest forms only (smoke test)
     rccl = diag["rccl"]
     assert 0 < len(rccl) <= 10 and any("nranks 2" in ln for ln in rccl) and any("version" in ln for ln in rccl), rccl
     _keep("bench_shared_gpu_arxiv_n2_rccl.json", out)
