@@ -489,7 +489,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("H2GCN_DIST_BACKEND", "nccl")  # "gloo" only for the shared-GPU test mode
-        timeout_s = float(os.environ.get("H2GCN_DIST_TIMEOUT_S", "120"))  # a failed rank must not hang its peers forever
+        # a failed rank must not hang its peers forever.  60 s: no collective of this run takes more than a few seconds (RCCL's
+        # communicator set-up on 8 GPUs: tens of seconds at most), and every hung exchange form costs this long plus the abort
+        timeout_s = float(os.environ.get("H2GCN_DIST_TIMEOUT_S", "60"))
         if backend == "nccl":
             from h2gcn_amd.partition import enable_rccl_debug_log, init_rccl_process_group
             # a collective that exceeds timeout_s: the watchdog tears the process down (SIGABRT) -- the supervisor's ladder

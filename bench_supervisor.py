@@ -216,7 +216,7 @@ def supervise(argv, rank: int, world: int) -> int:
     """Run this rank's worker(s) down the ladder; returns the exit code of the supervisor (0 = a value line was printed by
     rank 0's supervisor).  `argv` = bench.py's own command line (without the program name)."""
     # wall-clock limit of the first attempt (a healthy 8-rank run takes one to two minutes; a collective that never completes is
-    # torn down by the watchdog after H2GCN_DIST_TIMEOUT_S = 120 s: the budget is the backstop behind that) and of a retry
+    # torn down by the watchdog after H2GCN_DIST_TIMEOUT_S = 60 s: the budget is the backstop behind that) and of a retry
     budget_first = float(os.environ.get("H2GCN_BENCH_ATTEMPT_BUDGET_S", "420"))
     budget_retry = float(os.environ.get("H2GCN_BENCH_RETRY_BUDGET_S", os.environ.get("H2GCN_BENCH_ATTEMPT_BUDGET_S", "240")))
     budget0 = budget_first
@@ -286,7 +286,7 @@ def supervise(argv, rank: int, world: int) -> int:
         elif "H2GCN_BENCH_OMP_NUM_THREADS" in env:
             env["OMP_NUM_THREADS"] = env["H2GCN_BENCH_OMP_NUM_THREADS"]
         if k > 0:
-            env["H2GCN_DIST_TIMEOUT_S"] = os.environ.get("H2GCN_BENCH_RETRY_DIST_TIMEOUT_S", "90")
+            env["H2GCN_DIST_TIMEOUT_S"] = os.environ.get("H2GCN_BENCH_RETRY_DIST_TIMEOUT_S", os.environ.get("H2GCN_DIST_TIMEOUT_S", "60"))
         w = _Worker(cmd, env, tmp / f"attempt{k}.stdout")
         current["w"] = w
         t0 = time.monotonic()
