@@ -733,6 +733,7 @@ def main():
                                                       f"nnz(A1)={nnz_global[0]}, nnz(A2)={nnz_global[1]}, d={d}",
                                           "n_rows": n, "nnz_per_hop": nnz_global, "d": d, "dist_backend": backend,
                                           "parallelism": f"row-partition x{world}, exchange of X per step: {exchange}", "feature_chunks": spec}}}, rank)
+        injected_failure("after_timed", rank)
         if backend == "nccl" and rank == 0:
             from h2gcn_amd.partition import summarize_rccl_log
             try:

@@ -253,6 +253,20 @@ def supervise(argv, rank: int, world: int) -> int:
     for s_ in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
         signal.signal(s_, on_signal)
 
+    def report_failure(k_, why_):
+        """This rank's worker failed in attempt k_: its own record (with the time: the FIRST failure is what matters, a later one
+        is usually its consequence -- a peer's connection reset) plus the flag the other supervisors watch."""
+        store.set(f"a{k_}/failed_by{rank}", json.dumps({"t": time.time(), "why": f"rank {rank}: {why_}"}))
+        store.set(f"a{k_}/failed", "1")
+
+    def first_failure(k_):
+        recs = []
+        for q in range(world):
+            v = store.get(f"a{k_}/failed_by{q}", 0.0)
+            if v:
+                recs.append(json.loads(v))
+        return min(recs, key=lambda r: r["t"])["why"] if recs else None
+
     history = []          # rank 0: one entry per failed attempt
     final = 1
     for k in range(n_attempts):
@@ -328,13 +342,13 @@ def supervise(argv, rank: int, world: int) -> int:
                 continue
             if now - t0 > budget0:
                 why = f"no result within the attempt's budget of {budget0:.0f} s"
-                store.set(f"a{k}/failed", f"rank {rank}: {why}")
+                report_failure(k, why)
                 rc = w.kill()
                 break
             if peer_failed_at is None and store.has(f"a{k}/failed"):
                 peer_failed_at = now
             if peer_failed_at is not None and now - peer_failed_at > grace:
-                why = "taken down after a peer failed: " + (store.get(f"a{k}/failed", 1.0) or "?")
+                why = "taken down after a peer failed: " + (first_failure(k) or "?")
                 rc = w.kill()
                 break
             time.sleep(0.1)
@@ -344,7 +358,7 @@ def supervise(argv, rank: int, world: int) -> int:
             break
         if rc != 0 and why is None:
             why = _describe_rc(rc)
-            store.set(f"a{k}/failed", f"rank {rank}: {why}")
+            report_failure(k, why)
         store.set(f"a{k}/rc{rank}", rc)
         if rank != 0:
             verdict = store.get(f"a{k}/verdict", budget0 + 120.0)
@@ -385,7 +399,7 @@ def supervise(argv, rank: int, world: int) -> int:
         entry = {"attempt": k, "schedule": name, "rung": rung["rung"], "excluded": rung.get("excluded", []),
                  "in_flight_family": in_flight_family(attempt_entries),
                  "ranks": {str(q): ("ok" if v == 0 else _describe_rc(v)) for q, v in rcs.items()},
-                 "first_failure": died[0] if died else store.get(f"a{k}/failed", 0.1),
+                 "first_failure": died[0] if died else first_failure(k),
                  "calibration": [e for e in attempt_entries if "starting" not in e and "finished" not in e]}
         if line is not None and line.get("error"):
             entry["error_line"] = line["error"]

@@ -710,6 +710,21 @@ def test_bench_leaves_out_the_exchange_form_that_was_in_flight_when_a_rank_died(
     assert "ipc_kernel" in diag["attempts"][1]["schedule"] and diag["attempts"][1]["result"] == "ok"
 
 
+def test_bench_worker_dying_after_the_timed_region_leaves_its_measurement(tmp_path):
+    """Rank 0's worker dies right AFTER the K timed steps (before diagnostics, CPU legs and its print).  The measurement was put on
+    record the moment it existed; the supervisor rebuilds the line from it -- same contract keys, no second attempt."""
+    lines, err, rcs = _run_supervised(2, ["--chunks", "2"], {"H2GCN_BENCH_ABORT_RANK": "0", "H2GCN_BENCH_FAIL_STAGE": "after_timed"})
+    assert len(lines) == 1 and rcs == [0, 0], (lines, err[-3000:])
+    out = json.loads(lines[0])
+    assert out["metric"] == "aggregated edges/sec (1+2-hop SpMM)" and out["value"] > 0 and out["unit"] == "edges/s"
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["ms_per_step"] > 0
+    assert abs(out["value"] - sum(out["config"]["nnz_per_hop"]) / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    assert out["higher_is_better"] is True and out["scaling"] == "strong" and out["dtype"] == "f32" and out["data"] == "synthetic"
+    diag = out["config"]["diagnostics"]
+    assert "SIGABRT" in diag["rebuilt_by_supervisor"] and "attempts" not in diag
+    assert {e["calibration"] for e in diag["calibration"]} == {"allgather/2", "ipc_kernel/2"}
+
+
 def test_bench_rank_aborting_in_every_attempt_is_one_error_line(tmp_path):
     """The same injection honoured on every rung of the ladder: one error line (value null) that still carries every
     calibration entry that completed, as `partial`."""
