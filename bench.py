@@ -387,9 +387,8 @@ def self_launch(n_ranks):
             fail_line(ap, f"--gpus {n_ranks} but only {n_dev} GPU(s) are visible to this process")
         except SystemExit as e:
             return e.code
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    from bench_supervisor import _free_port
+    port = _free_port()          # (below the kernel's ephemeral range: see there)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
     env = dict(os.environ)

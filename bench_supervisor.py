@@ -85,7 +85,21 @@ def in_flight_family(entries):
 
 
 def _free_port() -> int:
-    with socket.socket() as sk:
+    """A TCP port for a rendezvous.  NOT one of the kernel's ephemeral ports (32768-60999 on Linux): those are what RCCL's and
+    gloo's own listening sockets and every outgoing connection of the job get, so a port that is free when probed can be taken a
+    moment later (seen once in 3 suite runs: EADDRINUSE on the store's port).  A random port below that range, verified by binding."""
+    import random
+
+    rng = random.Random(os.getpid() ^ int(time.time() * 1e6))
+    for _ in range(200):
+        port = rng.randrange(20000, 32000)
+        with socket.socket() as sk:
+            try:
+                sk.bind(("127.0.0.1", port))
+                return port
+            except OSError:
+                continue
+    with socket.socket() as sk:          # (every probe taken: let the kernel choose after all)
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
 
@@ -226,7 +240,7 @@ def supervise(argv, rank: int, world: int) -> int:
     total_budget = float(os.environ.get("H2GCN_BENCH_TOTAL_BUDGET_S", "1500"))      # all rungs together
     t_start = time.monotonic()
     try:
-        store = _Store(rank, world, timeout_s=max(60.0, budget0))
+        store = _Store(rank, world, timeout_s=90.0)      # (time to find the store: the supervisors start within seconds of each other)
     except Exception as e:  # noqa: BLE001 -- no key-value store to coordinate through: run the rank unsupervised rather than not at all
         print(json.dumps({"supervisor": f"rank {rank}: no store on {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} "
                                         f"({type(e).__name__}: {e}); running the rank without supervision"}), file=sys.stderr, flush=True)

@@ -62,9 +62,11 @@ if sc == "usage":
 
 
 def _free_port():
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
+    """A rendezvous port BELOW the kernel's ephemeral range (see bench_supervisor._free_port: ephemeral ports are what RCCL's and
+    gloo's own sockets get, so a probed-free one can be gone a moment later)."""
+    sys.path.insert(0, str(ROOT))
+    from bench_supervisor import _free_port as pick
+    return pick()
 
 
 def _env(tmp_path, scenario, **extra):

@@ -155,11 +155,11 @@ def test_halo_pull_fetches_only_the_named_rows_and_changes_no_bit(tmp_path, grap
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A rendezvous port BELOW the kernel's ephemeral range (see bench_supervisor._free_port: ephemeral ports are what RCCL's and
+    gloo's own sockets get, so a probed-free one can be gone a moment later)."""
+    sys.path.insert(0, str(ROOT))
+    from bench_supervisor import _free_port as pick
+    return pick()
 
 
 @pytest.mark.parametrize("exchange,chunks,backend", [("allgather", 1, "gloo"), ("allgather", 2, "gloo"), ("ipc_engine", 1, "gloo"),

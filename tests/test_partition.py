@@ -29,11 +29,12 @@ def test_block_bounds_cover_rows_exactly():
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A rendezvous port below the kernel's ephemeral range (see bench_supervisor._free_port)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from bench_supervisor import _free_port as pick
+    return pick()
 
 
 def _worker(rank, world, port, n, d, out_dir):

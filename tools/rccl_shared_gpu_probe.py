@@ -34,8 +34,9 @@ dist.destroy_process_group()
 
 def main():
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench_supervisor import _free_port
+    port = _free_port()          # below the kernel's ephemeral range (RCCL's own sockets take ephemeral ports)
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
