@@ -494,6 +494,23 @@ dist.barrier(); dist.destroy_process_group()
         assert all(p.returncode == 0 for p in procs) and all("TIMEOUT_OK" in o for o in outs), "\n".join(outs)
 
 
+def _reap(procs):
+    """Whatever happened (an assertion, a time-out): no rank process -- supervisor or worker -- outlives its test.  SIGTERM first: a
+    bench_supervisor takes its worker (own process group) down with it."""
+    import signal
+    import time
+    for p in procs:
+        if p.poll() is None:
+            p.send_signal(signal.SIGTERM)
+    deadline = time.time() + 10
+    for p in procs:
+        while p.poll() is None and time.time() < deadline:
+            time.sleep(0.1)
+        if p.poll() is None:
+            p.kill()
+            p.wait()
+
+
 def _run_bench(world, extra, tmp_path, env_extra=None):
     """bench.py as real subprocesses: `world` ranks sharing the one GPU (gloo bootstrap), returns the parsed JSON line."""
     port = _free_port()
@@ -510,7 +527,10 @@ def _run_bench(world, extra, tmp_path, env_extra=None):
         env.update(env_extra or {})
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--no-cpu-baseline",
                                        "--no-probe", "--no-traffic", "--no-hbm-leg"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
-    outs = [p.communicate(timeout=1500) for p in procs]
+    try:
+        outs = [p.communicate(timeout=400) for p in procs]
+    finally:
+        _reap(procs)
     assert all(p.returncode == 0 for p in procs), "\n".join(o[1].decode()[-3000:] for o in outs)
     lines = [l for l in outs[0][0].decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, outs[0][0].decode()
@@ -656,7 +676,7 @@ def test_bench_plain_launch_spawns_its_own_ranks(tmp_path, backend):
     _keep(f"bench_plain_launch_arxiv_n2_{backend}.json", out)
 
 
-def _run_supervised(world, extra, env_extra, timeout=1500):
+def _run_supervised(world, extra, env_extra, timeout=400):
     """`world` launcher-style ranks of bench.py sharing the box's GPU (each one a bench_supervisor with the real worker as its
     child); returns (stdout lines of rank 0, stderr of rank 0, exit codes)."""
     port = _free_port()
@@ -670,7 +690,10 @@ def _run_supervised(world, extra, env_extra, timeout=1500):
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--shape", "arxiv", "--steps", "2",
                                        "--warmup", "1", "--no-cpu-baseline", "--no-probe", "--no-traffic", "--no-hbm-leg", "--no-adjoint"] + extra,
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=timeout) for p in procs]
+    try:
+        outs = [p.communicate(timeout=timeout) for p in procs]
+    finally:
+        _reap(procs)
     for o in outs[1:]:
         assert o[0].strip() == "", o[0]
     return [ln for ln in outs[0][0].splitlines() if ln.strip()], outs[0][1], [p.returncode for p in procs]
