@@ -592,7 +592,7 @@ def main():
         exchanges = exchange_families(a)
         # every chunk width builds the canonical summation tree, so the checksum of Y is the same for every candidate and
         # equal to the 1-GPU line's; 32-column chunks (a short exposed head of the exchange) run as masked 64-column slices
-        chunk_specs = [a.chunks] if a.chunks else ["1", "2", "4", "32+32+64"]
+        chunk_specs = [a.chunks] if a.chunks else os.environ.get("H2GCN_BENCH_CHUNK_SPECS", "1,2,4,32+32+64").split(",")
         # SAFEST FIRST: one ncclAllGather per chunk and the library's own copy-kernel pulls are timed before anything whose
         # first contact with a second device could take the job down (grouped send/recv last); whatever is on record when
         # a later candidate dies is what the supervisor's line carries
@@ -640,7 +640,14 @@ def main():
             return bad
 
         cands = {}
+        # (a retry of the supervisor's ladder: candidates an earlier attempt already timed -- all but its fastest -- are not
+        # timed again; their figures travel in the line)
+        skip_keys = set(filter(None, os.environ.get("H2GCN_BENCH_SKIP_CANDIDATES", "").split(",")))
+        if os.environ.get("H2GCN_BENCH_EARLIER_TIMINGS"):
+            diagnostics["calibration_ms_per_step_in_an_earlier_attempt"] = json.loads(os.environ["H2GCN_BENCH_EARLIER_TIMINGS"])
         for ex, spec in pairs:
+            if f"{ex}/{spec}" in skip_keys:
+                continue
             widths = parse_chunks(spec, d)
             if isinstance(widths, int) and (d % widths or (widths > 1 and d // widths < 32)):
                 continue

@@ -63,9 +63,22 @@ def next_rung(history):
     fam, excluded = last.get("in_flight_family"), set(last.get("excluded") or [])
     if last["rung"] in ("requested", "exclude") and fam and fam != "allgather" and fam not in excluded and tried.count("exclude") < 2:
         ex = sorted(excluded | {fam})
+        env = {"H2GCN_BENCH_EXCLUDE_EXCHANGES": ",".join(ex), "H2GCN_BENCH_SKIP_DRY": "1"}
+        # economy: what earlier attempts already timed is on record -- keep the fastest of it (it has to be set up again to be
+        # usable) and do not re-time the rest; candidates that failed their correctness check stay out as well
+        cal = [e for h in history for e in h.get("calibration", []) if "calibration" in e]
+        timed = {e["calibration"]: e["ms_per_step"] for e in cal if "ms_per_step" in e}
+        usable = {k_: v for k_, v in timed.items() if k_.split("/")[0] not in ex}      # (the excluded form's own timings are moot)
+        if usable:
+            best = min(usable, key=usable.get)
+            skip = sorted((set(timed) | {e["calibration"] for e in cal if "rejected" in e}) - {best})
+            if skip:
+                env["H2GCN_BENCH_SKIP_CANDIDATES"] = ",".join(skip)
+                env["H2GCN_BENCH_EARLIER_TIMINGS"] = json.dumps({k_: timed[k_] for k_ in skip if k_ in timed})
         return {"rung": "exclude", "excluded": ex,
-                "name": f"as requested without the exchange form(s) {', '.join(ex)} (in flight when an attempt died); no first-contact table",
-                "env": {"H2GCN_BENCH_EXCLUDE_EXCHANGES": ",".join(ex), "H2GCN_BENCH_SKIP_DRY": "1"}}
+                "name": f"as requested without the exchange form(s) {', '.join(ex)} (in flight when an attempt died), earlier timings kept; "
+                        "no first-contact table",
+                "env": env}
     if "conservative" not in tried and "no_rccl" not in tried and fam != "allgather":
         return RUNG_CONSERVATIVE
     if "no_rccl" not in tried:

@@ -39,11 +39,16 @@ if sc in ("abort_first", "abort_twice", "abort_always"):
 if sc == "p2p_dies":          # the grouped send/recv form takes a rank down on first contact; the other forms are fine
     assert k < 2
     if "p2p" not in os.environ.get("H2GCN_BENCH_EXCLUDE_EXCHANGES", "").split(","):
-        prog({"starting": "allgather/2", "stage": "calibration"}); prog({"calibration": "allgather/2", "ms_per_step": 3.0})
-        prog({"finished": "allgather/2", "stage": "calibration"}); prog({"starting": "p2p/1", "stage": "calibration"})
+        for key, ms in (("allgather/2", 3.0), ("ipc_kernel/2", 1.0), ("allgather/1", 4.0)):
+            prog({"starting": key, "stage": "calibration"}); prog({"calibration": key, "ms_per_step": ms}); prog({"finished": key, "stage": "calibration"})
+        prog({"starting": "ipc_engine/1", "stage": "calibration"}); prog({"calibration": "ipc_engine/1", "rejected": "chunk 0 differs"})
+        prog({"finished": "ipc_engine/1", "stage": "calibration"}); prog({"starting": "p2p/1", "stage": "calibration"})
         if rank == 1: os.abort()
         time.sleep(600)
     assert os.environ.get("H2GCN_BENCH_SKIP_DRY") == "1" and "H2GCN_BENCH_FORCE_EXCHANGE" not in os.environ
+    # the fastest candidate of the dead attempt is kept, the others it had timed (and the one it had rejected) are not re-timed
+    assert os.environ["H2GCN_BENCH_SKIP_CANDIDATES"] == "allgather/1,allgather/2,ipc_engine/1", os.environ.get("H2GCN_BENCH_SKIP_CANDIDATES")
+    assert json.loads(os.environ["H2GCN_BENCH_EARLIER_TIMINGS"]) == {"allgather/1": 4.0, "allgather/2": 3.0}
     line(); sys.exit(0)
 if sc == "hang":
     if k == 0: time.sleep(600)
@@ -127,7 +132,7 @@ def test_the_form_in_flight_when_an_attempt_died_is_left_out_of_the_next_sweep(t
     assert diag["forced"] == [None, None, None]                       # a sweep, not a forced schedule
     first = diag["first_attempt"]
     assert first["in_flight_family"] == "p2p" and first["rung"] == "requested"
-    assert [e["calibration"] for e in first["calibration"]] == ["allgather/2"]
+    assert [e["calibration"] for e in first["calibration"]] == ["allgather/2", "ipc_kernel/2", "allgather/1", "ipc_engine/1"]
     assert "p2p" in diag["attempts"][-1]["schedule"] and diag["attempts"][-1]["result"] == "ok"
 
 

@@ -721,16 +721,23 @@ def test_bench_survives_a_rank_that_aborts(tmp_path):
 def test_bench_leaves_out_the_exchange_form_that_was_in_flight_when_a_rank_died(tmp_path):
     """Rank 1 dies INSIDE the ipc_kernel/2 candidate (started, never finished, in rank 0's record).  The next rung repeats the
     calibration sweep without that exchange form instead of falling straight back to the single conservative schedule."""
-    lines, err, rcs = _run_supervised(2, ["--chunks", "2"], {"H2GCN_BENCH_ABORT_RANK": "1", "H2GCN_BENCH_FAIL_STAGE": "candidate",
-                                                             "H2GCN_BENCH_FAIL_IN_CANDIDATE": "ipc_kernel/2"})
+    # chunkings 1 and 2: the order is allgather/2, ipc_kernel/2, allgather/1, ipc_kernel/1 -- rank 1 dies inside the last one
+    lines, err, rcs = _run_supervised(2, [], {"H2GCN_BENCH_ABORT_RANK": "1", "H2GCN_BENCH_FAIL_STAGE": "candidate",
+                                              "H2GCN_BENCH_FAIL_IN_CANDIDATE": "ipc_kernel/1", "H2GCN_BENCH_CHUNK_SPECS": "1,2"})
     assert len(lines) == 1 and rcs == [0, 0], (lines, err[-3000:])
     out = json.loads(lines[0])
     diag = out["config"]["diagnostics"]
     assert out["value"] > 0 and out["config"]["checksum_matches_n1"] is True and diag["exchange"] == "allgather"
     first = diag["first_attempt"]
     assert first["in_flight_family"] == "ipc_kernel" and first["ranks"]["1"] == "killed by SIGABRT"
-    assert [e["calibration"] for e in first["calibration"] if "ms_per_step" in e] == ["allgather/2"]
+    timed = {e["calibration"]: e["ms_per_step"] for e in first["calibration"] if "ms_per_step" in e}
+    assert list(timed) == ["allgather/2", "ipc_kernel/2", "allgather/1"]
     assert "ipc_kernel" in diag["attempts"][1]["schedule"] and diag["attempts"][1]["result"] == "ok"
+    # economy: the retry sets up and times only the faster of the two allgather chunkings the dead attempt had timed; the other
+    # one's figure travels in the line
+    best, other = sorted(("allgather/1", "allgather/2"), key=timed.get)
+    assert list(diag["calibration_ms_per_step"]) == [best]
+    assert diag["calibration_ms_per_step_in_an_earlier_attempt"] == {other: timed[other], "ipc_kernel/2": timed["ipc_kernel/2"]}
 
 
 def test_bench_worker_dying_after_the_timed_region_leaves_its_measurement(tmp_path):
