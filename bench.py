@@ -26,15 +26,37 @@ import torch.distributed as dist
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-#: order-independent fingerprint of Y (sum of the fp32 bit patterns as int64) of the default single-GPU line per (shape, d):
-#: the per-row summation tree is canonical, so EVERY schedule -- any rank count, exchange, chunking, slice width -- must
-#: reproduce it bit for bit (SURVEY.md 8(e) "Determinism"); N > 1 lines report `checksum_matches_n1` against this table
-#: (measured: BENCH_r03.json for products; the bench lines behind profiles/r04_*_summary.json for the rest)
+#: order-independent fingerprint of Y (sum of the fp32 bit patterns as int64) per (shape, d), computed by the ORACLE on the CPU:
+#: `python -m oracle.fullsize <shape>` rebuilds every row of the operands on the host and runs oracle_spmm_tree_f32_mt (the
+#: library's documented summation tree in plain C) -- profiles/r06_oracle_checksums_of_the_bench_shapes.txt; the arxiv entry is
+#: recomputed in the CPU suite, arxiv and products are asserted element by element on the GPU box
+#: (tests/test_fullsize_parity_gpu.py).  The per-row tree is canonical, so EVERY schedule -- any rank count, exchange, chunking,
+#: slice width -- must reproduce it bit for bit (SURVEY.md 8(e) "Determinism"): `checksum_matches_n1` is a comparison with the
+#: oracle, not with an earlier run of the HIP path.
 N1_CHECKSUMS = {("products", 128): -26948829970322352, ("products", 64): -13319257904282617, ("arxiv", 128): -1390319019045034,
                 ("h2gcn_like", 128): -20343064339982979, ("products_tail", 128): -25034865256373447,
                 ("lowdeg", 128): -57806506298044835, ("hbm16m", 128): -132311004237956237, ("products_x6", 128): -179026745709730822}
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
+
+
+def peak_source(pr):
+    """"confirm on the box".  `roofline.peak` stays the guide's spec constant (what every fraction of every round
+    is quoted against); next to it goes what THIS box reports about its memory system -- hipDeviceProp_t's memory clock and bus
+    width, read by tools/gather_probe -- and the rate they imply: bus_width / 8 x clock x transfers per reported clock.  The
+    runtime reports the HBM command clock; HBM3 / HBM3E move 4 transfers per pin per such clock (MI300X: 1300 MHz x 8192 bit x 4
+    = 5.3 TB/s = its spec), so that is the factor used; the 2x reading is carried too."""
+    clk, width = (pr or {}).get("memory_clock_khz"), (pr or {}).get("memory_bus_width_bits")
+    if not clk or not width:
+        return {"peak_source": "spec constant (MI355X_MICROARCH.md: HBM3E 8.0 TB/s); the box reported no memory clock / bus width",
+                "peak_confirmed_on_box": False}
+    per_clock = clk * 1e3 * width / 8 / 1e9
+    derived = 4 * per_clock
+    ok = abs(derived / HBM_PEAK_GBPS - 1.0) <= 0.05
+    return {"peak_source": f"spec constant (MI355X_MICROARCH.md: HBM3E 8.0 TB/s); this box ({pr.get('device_name')}, {pr.get('gcn_arch')}) reports "
+                           f"memory clock {clk / 1e3:.0f} MHz x bus {width} bit -> {derived:.0f} GB/s at 4 transfers/clock "
+                           f"({2 * per_clock:.0f} at 2): " + ("confirms the constant" if ok else "does NOT match the constant within 5 %"),
+            "peak_confirmed_on_box": ok, "peak_box_memory_clock_khz": clk, "peak_box_bus_width_bits": width, "peak_box_derived_GBps": derived}
 
 
 def algorithmic_bytes(nnz_list, n_rows_out, d, n_hops):
@@ -193,6 +215,33 @@ def measure_traffic_live(a, timeout_s=240):
             "read_bytes": 2 * out["FETCH_SIZE"] * 1024 * launches_per_step, "write_bytes": out["WRITE_SIZE"] * 1024 * launches_per_step,
             "source": "LIVE: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command on this box "
                       "(2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 per step; FETCH_SIZE counts L2 misses, i.e. Infinity-Cache hits too)"}
+
+
+def secondary_leg(shape, steps=200, warmup=20, timeout_s=300):
+    """BASELINE configs[2] (the arxiv shape: an Infinity-Cache-resident 0.2 ms launch) next to the headline in the SAME default
+    line: a child run of this script after the timed region -- kernel time from the hip events around each launch, the PMC traffic
+    from its own two rocprofv3 passes.  Reported under `secondary` (+ scalars under `roofline`); never part of `value`."""
+    import subprocess
+
+    child = [sys.executable, str(ROOT / "bench.py"), "--shape", shape, "--steps", str(steps), "--warmup", str(warmup),
+             "--no-cpu-baseline", "--no-adjoint", "--no-hbm-leg", "--no-probe", "--no-secondary"]
+    try:
+        env = {k: v for k, v in os.environ.items() if k != "H2GCN_BENCH_CHILD"}     # the child collects its own PMC passes
+        r = subprocess.run(child, env=env, capture_output=True, text=True, timeout=timeout_s)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"child exited with {r.returncode}: {r.stderr[-300:]}"}
+        c = json.loads(line[-1])
+        rf = c["roofline"]
+        return {"workload": c["config"]["workload"], "steps": c["steps"], "warmup": c["warmup"], "ms_per_step": c["ms_per_step"],
+                "edges_per_s": c["value"], "kernel_ms": rf["kernel_ms"], "kernel_ms_median": rf["kernel_ms_median"],
+                "achieved_GBps": rf["achieved"], "frac": rf["frac"], "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
+                "traffic": rf.get("traffic"), "traffic_over_algorithmic": rf.get("traffic_over_algorithmic"),
+                "traffic_source": rf.get("traffic_source"), "segment_walk": c["config"]["schedule"].get("segment_walk"),
+                "checksum_matches_n1": c["config"].get("checksum_matches_n1"),
+                "source": f"LIVE child run of `bench.py --shape {shape} --steps {steps} --warmup {warmup}` on this box after the timed region"}
+    except Exception as e:  # noqa: BLE001 -- a report, never a reason to lose the GPU number
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 HBM_LEG_STEPS = 12   # timed launches of the HBM-resident leg (after 2 warm-ups)
@@ -448,6 +497,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--pad-rows", action="store_true",
                     help="give X a row stride padded to 32 floats (every row starts on a 128-byte line), as the model's concat buffer has")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the BASELINE configs[2] (arxiv shape) leg that the default products line carries under `secondary` "
+                         "(--no-hbm-leg skips it too: no child legs at all)")
     ap.add_argument("--no-hbm-leg", action="store_true",
                     help="skip the HBM-resident leg (products_x6, 12 steps, child process) the default N=1 products line carries")
     ap.add_argument("--dry-exchange", action="store_true",
@@ -506,7 +558,8 @@ def main():
             # what RCCL chose (channels, transports, algorithm/protocol) goes to a file per process, summarised into the line
             import tempfile
             rccl_log_dir = os.environ.get("H2GCN_BENCH_SCRATCH") or tempfile.mkdtemp(prefix="h2gcn_rccl_", dir="/tmp")
-            enable_rccl_debug_log(rccl_log_dir)
+            # (per-collective TUNING lines only in the stand-alone first-contact run: they are file I/O on the launching thread)
+            enable_rccl_debug_log(rccl_log_dir, tuning=True if a.dry_exchange else None)
             init_rccl_process_group(device, timeout_s)
         else:
             import datetime
@@ -605,27 +658,32 @@ def main():
         # candidate is checked with TWO different inputs (the second exchange must not serve the first one's bytes again)
         # before it is timed, and its Y against the single-GPU checksum: a fast schedule that moves wrong bytes is rejected.
         x_alt_local = synth.synth_features(d, synth.SEED_X + 1, r0, r1, device)
-        x_ref = {synth.SEED_X + 1: synth.synth_features(d, synth.SEED_X + 1, 0, n, device), synth.SEED_X: synth.synth_features(d, synth.SEED_X, 0, n, device)}
         want_ck = [N1_CHECKSUMS.get((a.shape, d))]
 
         def exchange_is_exact(cand):
-            """None, or why this rank rejects the candidate.  Every rank takes the same path through the one collective."""
+            """None, or why this rank rejects the candidate.  Every rank takes the same path through the one collective.  The
+            reference rows are regenerated one peer block at a time (the generator yields any rows): nothing of the size of X is
+            held besides the exchange's own buffers -- row partitioning is there to divide that memory, not to triple it."""
             bad = None
             try:
                 for seed, xl in ((synth.SEED_X + 1, x_alt_local), (synth.SEED_X, x_local)):
                     cand(xl, out=y)
                     torch.cuda.synchronize()
-                    for c in range(cand.C):
-                        got, want = cand.full[c][:n], x_ref[seed][:, cand.offsets[c]:cand.offsets[c] + cand.widths[c]]
-                        if cand.halo is None:
-                            if bad is None and not torch.equal(got, want):
-                                bad = f"chunk {c}: the gathered embedding differs from X (input seed {seed})"
-                            continue
-                        for q in range(world):   # halo pulls: only the rows this rank's hop matrices name arrive
-                            q0, q1 = block_bounds(n, world, q)
-                            rows = torch.arange(q0, q1, device=device) if q == rank else (cand.halo[q].to(torch.int64) + q0)
+                    for q in range(world):
+                        q0, q1 = block_bounds(n, world, q)
+                        want_blk = synth.synth_features(d, seed, q0, q1, device)
+                        for c in range(cand.C):
+                            got = cand.full[c][q0:q1]
+                            want = want_blk[:, cand.offsets[c]:cand.offsets[c] + cand.widths[c]]
+                            if cand.halo is None:
+                                if bad is None and not torch.equal(got, want):
+                                    bad = f"chunk {c}: rank {q}'s block of the gathered embedding differs from X (input seed {seed})"
+                                continue
+                            # halo pulls: only the rows this rank's hop matrices name arrive (all of its own block)
+                            rows = torch.arange(0, q1 - q0, device=device) if q == rank else cand.halo[q].to(torch.int64)
                             if bad is None and rows.numel() and not torch.equal(got[rows], want[rows]):
                                 bad = f"chunk {c}: named rows of rank {q}'s block differ from X (input seed {seed})"
+                        del want_blk
                 if cand.ipc is not None:
                     cand.ipc.check()
             except Exception as e:  # noqa: BLE001
@@ -693,7 +751,7 @@ def main():
             progress({"finished": key, "stage": "calibration"}, rank)
             if len(cands) == 1:
                 injected_failure("calibration", rank)
-        del x_alt_local, x_ref
+        del x_alt_local
         if not cands:
             fail_line(a, f"no exchange schedule works on this node: {rejected}", rank)
         best = min(cands, key=lambda k: cands[k][0])
@@ -865,6 +923,12 @@ def main():
         out["roofline"]["hbm_resident_kernel_ms_min"] = leg.get("kernel_ms_min")
         out["roofline"]["hbm_resident_kernel_ms_max"] = leg.get("kernel_ms_max")
         out["roofline"]["hbm_resident_steps"] = leg.get("steps")
+    if (rank == 0 and world == 1 and a.shape == "products" and not (a.no_secondary or a.no_hbm_leg) and os.environ.get("H2GCN_BENCH_CHILD") != "1"
+            and not any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ)):
+        leg2 = secondary_leg("arxiv")
+        out["secondary"] = {"arxiv_d128": leg2}
+        for k_ in ("kernel_ms", "frac", "traffic_over_algorithmic"):     # scalars a flattening reader keeps
+            out["roofline"][f"arxiv_d128_{k_}"] = leg2.get(k_)
     if world > 1:
         layer.close()          # collective: release the exchange buffers before rank 0 spends its seconds on the CPU legs
     if rank == 0 and not a.no_probe:
@@ -874,6 +938,7 @@ def main():
         out["roofline"]["gather_ceiling_GBps"] = pr.get("gather_GBps")
         out["roofline"]["peak_achievable"] = max(pr.get("copy_GBps") or 0.0, pr.get("stream_read_GBps") or 0.0) or None
         out["roofline"]["ceilings"] = pr
+        out["roofline"].update(peak_source(pr))
         if pr.get("gather_GBps"):
             out["roofline"]["achieved_over_gather_ceiling"] = achieved / pr["gather_GBps"]
     if rank == 0 and world > 1 and out["roofline"]["traffic"] is None:
@@ -901,10 +966,16 @@ def main():
             store = dist.distributed_c10d._get_default_store()
             if rank == 0:
                 store.set("h2gcn_bench/line_printed", "1")
+                for q in range(1, world):      # bounded: the store lives in this process and must outlive the peers' look at it
+                    try:
+                        store.wait([f"h2gcn_bench/seen{q}"], datetime.timedelta(seconds=5))
+                    except Exception:  # noqa: BLE001 -- a peer that is gone already does not need the store
+                        break
             else:
                 store.wait(["h2gcn_bench/line_printed"], datetime.timedelta(seconds=1800))
-        except Exception:  # noqa: BLE001 -- store API unavailable: the collective form
-            dist.barrier()
+                store.set(f"h2gcn_bench/seen{rank}", "1")
+        except Exception as e:  # noqa: BLE001 -- the measurement is printed; NO collective from here (rank 0 may be gone already)
+            print(f"rank {rank}: final store hand-shake: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
         dist.destroy_process_group()
 
 

@@ -272,9 +272,16 @@ def supervise(argv, rank: int, world: int) -> int:
             current["w"].kill(1.0)
         if rank == 0 and not printed["line"]:
             printed["line"] = True
-            print(json.dumps({"metric": METRIC, "value": None, "unit": "edges/s", "n_gpus": world,
+            # os.write, not print: the main thread may be inside a print of its own (a signal handler must not re-enter the
+            # buffered stream); one write call = one line
+            txt = json.dumps({"metric": METRIC, "value": None, "unit": "edges/s", "n_gpus": world,
                               "error": f"supervisor received {signal.Signals(signum).name}",
-                              "partial": _progress_entries(tmp / "progress.jsonl")}), flush=True)
+                              "partial": _progress_entries(tmp / "progress.jsonl")}) + "\n"
+            try:
+                sys.stdout.flush()
+            except Exception:  # noqa: BLE001
+                pass
+            os.write(1, txt.encode())
         os._exit(128 + signum)
 
     for s_ in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
@@ -456,8 +463,12 @@ def supervise(argv, rank: int, world: int) -> int:
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)
     # a store hosted by rank 0's supervisor must outlive the other supervisors' last look at it
-    store.set(f"bye{rank}", 1)
-    if store.hosted:
-        for q in range(1, world):
-            store.get(f"bye{q}", 30.0)
+    # (a peer may need teardown + kill grace before it says bye; a store that is gone already is nobody's error -- the line is out)
+    try:
+        store.set(f"bye{rank}", 1)
+        if store.hosted:
+            for q in range(1, world):
+                store.get(f"bye{q}", teardown + 13.0 + 12.0)
+    except Exception:  # noqa: BLE001
+        pass
     return final

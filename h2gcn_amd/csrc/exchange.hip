@@ -24,6 +24,34 @@
 // would.  Copy-engine mode keeps host-side sequence numbers (hipMemcpyAsync needs its source address on the host) and
 // cannot be captured.
 //
+// Visibility across devices -- why a peer that sees flag >= q reads the bytes of step q, and what a one-GPU test box cannot show.
+//   The slots are ordinary (coarse-grained) hipMalloc memory: while stage_kernel runs, its stores may sit dirty in the L2 of
+//   whichever of the 8 XCDs ran the workgroup -- and the 8 L2s are NOT coherent with each other, let alone with a remote device,
+//   which reads this memory over xGMI at its home (the memory side: Infinity Cache / HBM), never through the owner's L2s.
+//   (1) WRITER, release.  stage_kernel and signal_kernel are two dispatches on ONE stream.  A dispatch boundary on a multi-XCD
+//       part ends with a release of at least agent scope: every XCD's L2 writes its dirty lines back to the memory side
+//       (without that, kernel B on XCD 1 could not read what kernel A wrote on XCD 0 -- ordinary same-stream producer/consumer
+//       code relies on it).  So when signal_kernel STARTS, the whole slot is at its home, on every XCD.  signal_kernel's own
+//       __threadfence_system() is not what publishes the slot (it runs on one XCD and can only write back that one L2); it
+//       orders signal_kernel's OWN flag stores behind everything this device did before, and the flag stores are system-scope
+//       release stores into the peer's UNCACHED flag words.  The slot is therefore at its home before any flag says q.
+//   (2) hipGraph replay keeps (1): a captured stream dependency stage -> signal becomes a graph edge; kernel nodes joined by an
+//       edge are dispatched with the barrier bit and the same end-of-kernel release as on a stream.  Nothing here relies on
+//       host-side ordering.
+//   (3) READER, acquire.  One wave per pull workgroup spins on its LOCAL uncached flag with system-scope acquire loads; after
+//       the workgroup barrier EVERY wave executes a system-scope acquire fence (buffer_inv sc0 sc1: drops the non-local lines
+//       of its CU's L1 and its XCD's L2), so a line of the peer's slot cached two steps ago (same slot parity) cannot be
+//       served; the pull loads are non-temporal on top.  Every XCD that runs a pull workgroup invalidates for itself.
+//       Copy-engine mode: the wait kernel's acquire precedes an SDMA copy, which reads the peer's memory without the CU caches.
+//   (4) The pulled bytes land in `full` (local memory) and reach the SpMM through a stream / event / graph edge: (1) again.
+//   With every rank on ONE device (the test box) all of this traffic has the same home and the same L2s, so (1) and (3) are
+//   exercised but can never FAIL there: a missing write-back or invalidate would be invisible.  That is the one property of
+//   this file no test on this box can pin.  It is therefore gated at run time instead: the first time a training run builds an
+//   IPC pipeline, partition.ShardedHops gathers two test patterns through it AND through ncclAllGather and compares the
+//   results on every rank (one collective each, outside any capture); a mismatch -- H2GCN_XCHG_INJECT_STALE=1 fakes one by
+//   not updating the slot from the second step on -- switches the run to the `allgather` exchange with a warning.  bench.py
+//   gates every IPC candidate the same way (against the regenerated embedding) before it is timed.
+//
 // Deadlock freedom: signal(q) is enqueued before any wait(q) of the same rank, and everything enqueued before
 // signal(q) depends only on signals < q of the peers -- induction over (step, channel) order, independent of how
 // HIP maps streams onto hardware queues.  A peer that dies leaves waits that give up after `timeout_ms`.
@@ -84,7 +112,7 @@ struct SeqRef {
 
 template <bool VEC4>
 __global__ void stage_kernel(const float* __restrict__ src, int64_t ld_src, int64_t rows, int64_t rows_per_rank,
-                             int width, char* data, size_t slot_bytes, int channel, SeqRef seq, float* __restrict__ own) {
+                             int width, char* data, size_t slot_bytes, int channel, SeqRef seq, float* __restrict__ own, int skip_slot) {
     using T = typename std::conditional<VEC4, float4, float>::type;
     float* __restrict__ slot = reinterpret_cast<float*>(data + ((size_t)channel * 2 + (seq.next() & 1u)) * slot_bytes);
     const int wv = VEC4 ? width / 4 : width;
@@ -95,7 +123,7 @@ __global__ void stage_kernel(const float* __restrict__ src, int64_t ld_src, int6
         T v;
         if constexpr (VEC4) v = make_float4(0.f, 0.f, 0.f, 0.f); else v = 0.f;
         if (r < rows) v = *reinterpret_cast<const T*>(src + r * ld_src + (int64_t)c * (VEC4 ? 4 : 1));
-        reinterpret_cast<T*>(slot)[i] = v;
+        if (!skip_slot) reinterpret_cast<T*>(slot)[i] = v;   // (skip_slot: failure injection, see H2GCN_XCHG_INJECT_STALE)
         reinterpret_cast<T*>(own)[i] = v;
     }
 }
@@ -295,6 +323,7 @@ struct h2gcn_xchg {
     int* err = nullptr;         // host-mapped: set by a wait that gave up
     uint32_t* seq_dev = nullptr;  // copy-kernel mode: [3][kMaxChannels] device counters: post_seq, pull_seq, pull_done
     bool connected = false;
+    bool inject_stale = false;  // H2GCN_XCHG_INJECT_STALE=1 (tests): see allgather_impl
     PeerTable peers;
     std::vector<void*> opened;          // pointers to close with hipIpcCloseMemHandle
     std::vector<hipStream_t> streams;   // [world]; entry `rank` is the copy-kernel stream
@@ -415,6 +444,10 @@ int h2gcn_xchg_create(int world, int rank, int n_channels, size_t slot_bytes, in
         x->mode = mode;
         x->slot_bytes = (slot_bytes + 255) / 256 * 256;  // keep every slot 256-B aligned
         x->timeout_ticks = (long long)(timeout_ms > 0 ? timeout_ms : 10000) * 100000LL;  // wall_clock64: 100 MHz
+        {
+            const char* inj = getenv("H2GCN_XCHG_INJECT_STALE");
+            x->inject_stale = inj && inj[0] == '1';
+        }
         memset(&x->peers, 0, sizeof(x->peers));
         H2GCN_HIP_TRY(hipGetDevice(&x->device));
         H2GCN_HIP_TRY(hipMalloc((void**)&x->data, x->slot_bytes * 2 * (size_t)n_channels));
@@ -562,12 +595,15 @@ static int allgather_impl(h2gcn_xchg_t* x, int channel, const float* src, int64_
             const bool vec4 = width % 4 == 0 && ld_src % 4 == 0 && ((uintptr_t)src & 15u) == 0 && ((uintptr_t)own & 15u) == 0;
             const int64_t total = rows_per_rank * (vec4 ? width / 4 : width);
             const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+            // failure injection for the run-time gate of the IPC exchange (see "Visibility across devices"): from the second step
+            // of a channel on, the slot is NOT updated -- the peers pull what an earlier step (or nobody) left there
+            const int skip_slot = (x->inject_stale && seq >= 2) ? 1 : 0;
             if (vec4)
                 hipLaunchKernelGGL(stage_kernel<true>, dim3(blocks), dim3(256), 0, stream, src, ld_src, rows, rows_per_rank,
-                                   (int)width, x->data, x->slot_bytes, channel, sr, own);
+                                   (int)width, x->data, x->slot_bytes, channel, sr, own, skip_slot);
             else
                 hipLaunchKernelGGL(stage_kernel<false>, dim3(blocks), dim3(256), 0, stream, src, ld_src, rows, rows_per_rank,
-                                   (int)width, x->data, x->slot_bytes, channel, sr, own);
+                                   (int)width, x->data, x->slot_bytes, channel, sr, own, skip_slot);
             H2GCN_HIP_TRY(hipGetLastError());
         }
         if (x->world > 1) {

@@ -470,7 +470,10 @@ __device__ __forceinline__ void store_vec(float* p, const float (&acc)[VEC]) {
         typename VecT<VEC>::type o;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) o[i] = acc[i];
-#ifdef H2GCN_PLAIN_STORES   // A/B builds only (profiles/r04_ab_output_stores.txt)
+#if defined(H2GCN_AB_NO_STORES)   // A/B builds only (profiles/r06_ab_forward_vs_adjoint_x6.txt): every sum is computed, the output
+        if (acc[0] == 1.2345678e30f)   // stream is not issued (the comparison keeps the arithmetic alive and is never true)
+            __builtin_nontemporal_store(o, reinterpret_cast<typename VecT<VEC>::type*>(p));
+#elif defined(H2GCN_PLAIN_STORES)   // A/B builds only (profiles/r04_ab_output_stores.txt)
         *reinterpret_cast<typename VecT<VEC>::type*>(p) = o;
 #else
         __builtin_nontemporal_store(o, reinterpret_cast<typename VecT<VEC>::type*>(p));

@@ -24,7 +24,8 @@ class KerasAdam(torch.optim.Optimizer):
         if lr < 0 or not 0 <= beta_1 < 1 or not 0 <= beta_2 < 1 or epsilon < 0:
             raise ValueError(f"KerasAdam: lr {lr}, beta_1 {beta_1}, beta_2 {beta_2}, epsilon {epsilon}")
         super().__init__(params, dict(lr=lr, beta_1=beta_1, beta_2=beta_2, epsilon=epsilon))
-        self._l2 = {}   # id(param) -> coefficient of a keras-style l2 regulariser folded into the step (see set_l2)
+        self._zero_grads = {}
+        self._l2 = {}   # param (tensors hash by identity, like self.state's keys) -> coefficient of a keras-style l2 regulariser folded into the step (see set_l2)
 
     def set_l2(self, params, coefficient: float) -> None:
         """Fold the gradient of ``coefficient * sum(p ** 2)`` (keras ``regularizers.l2``, reference ``H2GCN.py:239-240,247-248``)
@@ -34,7 +35,7 @@ class KerasAdam(torch.optim.Optimizer):
         if coefficient < 0:
             raise ValueError(f"KerasAdam.set_l2: coefficient {coefficient}")
         for p in params:
-            self._l2[id(p)] = float(coefficient)
+            self._l2[p] = float(coefficient)
             if p.is_cuda and _capi.has("h2gcn_l2_penalty_workspace_bytes"):
                 # the step closures report the penalty's VALUE through l2_penalty(): its scratch must exist (and be zero) BEFORE
                 # any hipGraph capture -- a buffer first allocated inside a capture lives in the graph's private pool, its zero-fill
@@ -48,6 +49,14 @@ class KerasAdam(torch.optim.Optimizer):
             st["v"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st
 
+    def _zero_grad_of(self, p):
+        """The all-zero data gradient of a regularised kernel that did not take part in the loss: one buffer per parameter, made
+        once (nothing writes to it), not one allocation per step.  Kept outside ``self.state`` (not optimizer state)."""
+        z = self._zero_grads.get(p)
+        if z is None:
+            z = self._zero_grads[p] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return z
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -58,7 +67,8 @@ class KerasAdam(torch.optim.Optimizer):
             lr, b1, b2, eps = group["lr"], group["beta_1"], group["beta_2"], group["epsilon"]
             # a kernel registered with set_l2 whose data gradient is absent (it did not take part in this loss) still owes the
             # penalty's 2*l2*w -- what autograd would have produced had the penalty been part of the loss: step it on zeros
-            ps = [p for p in group["params"] if p.grad is not None or self._l2.get(id(p), 0.0)]
+            # (a FROZEN kernel -- requires_grad False -- is left alone: frozen means no update, penalty included)
+            ps = [p for p in group["params"] if p.grad is not None or (p.requires_grad and self._l2.get(p, 0.0))]
             if not ps:
                 continue
             # one step counter per group, on the device of its first parameter (host copy for the CPU formula)
@@ -68,12 +78,12 @@ class KerasAdam(torch.optim.Optimizer):
             fast = [p for p in ps if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.device == group["step_dev"].device]
             slow = [p for p in ps if not any(p is q for q in fast)]
             if fast:
-                grads = [torch.zeros_like(p, memory_format=torch.contiguous_format) if p.grad is None else
+                grads = [self._zero_grad_of(p) if p.grad is None else
                          (p.grad if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else p.grad.to(torch.float32).contiguous()) for p in fast]
                 states = [self._state(p) for p in fast]
                 n = len(fast)
                 arr = C.c_void_p * n
-                l2s = [self._l2.get(id(p), 0.0) for p in fast]
+                l2s = [self._l2.get(p, 0.0) for p in fast]
                 with torch.cuda.device(fast[0].device):
                     stream = torch.cuda.current_stream(fast[0].device).cuda_stream
                     common = (n, arr(*[p.data_ptr() for p in fast]), arr(*[g.data_ptr() for g in grads]),
@@ -96,8 +106,8 @@ class KerasAdam(torch.optim.Optimizer):
                 one, tb1, tb2 = (torch.tensor(x, dtype=torch.float32) for x in (1.0, b1, b2))   # fp32 like the kernel
                 alpha = (torch.tensor(lr, dtype=torch.float32) * torch.sqrt(one - tb2 ** t) / (one - tb1 ** t)).item()
                 g = p.grad if p.grad is not None else torch.zeros_like(p)
-                if self._l2.get(id(p), 0.0):
-                    g = g + p * (2.0 * self._l2[id(p)])
+                if self._l2.get(p, 0.0):
+                    g = g + p * (2.0 * self._l2[p])
                 st["m"].add_((g - st["m"]) * (one - tb1).item())
                 st["v"].add_((g * g - st["v"]) * (one - tb2).item())
                 p.sub_((st["m"] * alpha) / (st["v"].sqrt() + eps))

@@ -49,17 +49,24 @@ def init_rccl_process_group(device: torch.device, timeout_s: Optional[float] = N
         dist.init_process_group("nccl", device_id=device, **kw)
 
 
-def enable_rccl_debug_log(directory: str) -> None:
-    """Have RCCL write what it decides at communicator set-up (topology graph, channels, transports) and per collective
-    (algorithm / protocol) into one FILE per process under ``directory`` -- never to stdout/stderr.  Must run before the
-    process group is created.  Ring-vs-direct is what decides the 8-GPU outcome of the per-layer all-gather
-    (SURVEY.md §7), so a multi-rank run keeps this next to its number.  A level below INFO that is already in the environment
-    (this image exports NCCL_DEBUG=VERSION, which makes RCCL print its banner to STDOUT) is raised to INFO; a more verbose
-    level, a subsystem list or a file name the caller chose are kept."""
+def enable_rccl_debug_log(directory: str, tuning: Optional[bool] = None) -> None:
+    """Have RCCL write what it decides at communicator set-up (topology graph, channels, transports) into one FILE per process
+    under ``directory`` -- never to stdout/stderr.  Must run before the process group is created.  Ring-vs-direct is what decides
+    the 8-GPU outcome of the per-layer all-gather, so a multi-rank run keeps this next to its number.
+
+    ``tuning`` adds the TUNING subsystem: one "AllGather: N Bytes -> Algo ... proto ..." line (a write + flush on the launching
+    thread) per collective ENQUEUE.  That is I/O inside a timed step, so a measuring run leaves it off (default: off unless
+    ``H2GCN_RCCL_LOG_TUNING=1``); the stand-alone first-contact table (``bench.py --dry-exchange``), which times nothing that is
+    reported as the metric, turns it on.  INIT + GRAPH write at communicator set-up only.
+
+    ``NCCL_DEBUG``: this image exports VERSION, which makes RCCL print its banner to STDOUT -- raised to INFO (the file takes it);
+    WARN, or a more verbose level, a subsystem list or a file name the caller chose are kept."""
     os.makedirs(directory, exist_ok=True)
-    if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE", "ABORT"):
+    if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE", "ABORT", "WARN"):
         os.environ["NCCL_DEBUG"] = "INFO"
-    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING")
+    if tuning is None:
+        tuning = os.environ.get("H2GCN_RCCL_LOG_TUNING") == "1"
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING" if tuning else "INIT,GRAPH")
     os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(directory, "rccl.%h.%p"))
 
 
@@ -894,6 +901,7 @@ class ShardedHops:
         self.n_hops, self.n_rows, self.n_cols = plan.n_hops, plan.n_rows, plan.n_cols
         self.partition = partition
         self._pipes = {}
+        self.verify_fallback = None  # why the IPC exchange was replaced by the all-gather (see pipeline), if it was
         self._small = None          # (IpcExchange, scratch) of all_reduce_small
         self._small_views = {}
 
@@ -902,13 +910,72 @@ class ShardedHops:
             chunks = 1
             while chunks * 2 <= self.max_chunks and d % (chunks * 2) == 0 and d // (chunks * 2) >= self.chunk_cols:
                 chunks *= 2
-            self._pipes[d] = PipelinedHopAggregation(self.plan, self.n_global, d, chunks, self.device, self.group,
-                                                     exchange=self.exchange if self.device.type == "cuda" or not self.exchange.startswith("ipc_") else "allgather",
-                                                     partition=self.partition,
-                                                     # training: a rank may legitimately stall for a long time (first-epoch
-                                                     # module loads, rank 0 writing a checkpoint) -- two minutes by default
-                                                     ipc_timeout_ms=int(os.environ.get("H2GCN_XCHG_TIMEOUT_MS", "120000")))
+
+            def build(exchange):
+                return PipelinedHopAggregation(self.plan, self.n_global, d, chunks, self.device, self.group,
+                                               exchange=exchange if self.device.type == "cuda" or not exchange.startswith("ipc_") else "allgather",
+                                               partition=self.partition,
+                                               # training: a rank may legitimately stall for a long time (first-epoch
+                                               # module loads, rank 0 writing a checkpoint) -- two minutes by default
+                                               ipc_timeout_ms=int(os.environ.get("H2GCN_XCHG_TIMEOUT_MS", "120000")))
+
+            pipe = build(self.exchange)
+            if pipe.ipc is not None and pipe.world > 1 and os.environ.get("H2GCN_XCHG_VERIFY", "1") != "0":
+                # the run-time gate of csrc/exchange.hip ("Visibility across devices"): what one shared GPU cannot test is
+                # checked where it matters -- on the node the run is on, before the first real exchange
+                why = self._ipc_exchange_mismatch(pipe)
+                if why is not None:
+                    import warnings
+                    warnings.warn(f"h2gcn_amd: the IPC exchange ({self.exchange}) does not reproduce an all-gather of the same tensor on this "
+                                  f"node ({why}); this run uses exchange='allgather' instead (no hipGraph replay of row-partitioned steps)")
+                    pipe.close()                      # collective: every rank took the same decision (all-reduced verdict)
+                    self.exchange = "allgather"
+                    self.verify_fallback = why
+                    pipe = build("allgather")
+            self._pipes[d] = pipe
         return self._pipes[d]
+
+    def _ipc_exchange_mismatch(self, pipe: "PipelinedHopAggregation") -> Optional[str]:
+        """Collective, eager (never inside a capture): gather TWO different test patterns through the pipeline's IPC exchange (both
+        slot parities; the second must not deliver the first one's bytes) and through the process group's all-gather, compare on
+        every rank, all-reduce the verdict.  None = identical everywhere; otherwise what differed (same string on every rank)."""
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ShardedHops: the first use of an IPC pipeline must happen outside a hipGraph capture (run a warm-up step)")
+        dev, n_local = self.device, pipe.r1 - pipe.r0
+        bad = 0
+        rows = torch.arange(pipe.r0, pipe.r1, device=dev, dtype=torch.int64)[:, None]
+        for trial in (1, 2):
+            for c, w in enumerate(pipe.widths):
+                cols = torch.arange(w, device=dev, dtype=torch.int64)[None, :] + pipe.offsets[c]
+                x = ((rows * 131 + cols * 7 + trial * 1000003) % 65521).to(torch.float32)
+                pipe.ipc.begin(c, x, pipe.full[c], pipe.per, pull=False)
+                pipe.ipc.pull(c, pipe.full[c], pipe.per, halo=pipe.halo)
+                pipe.ipc.end(c)
+                send = torch.zeros((pipe.per, w), dtype=torch.float32, device=dev)
+                send[:n_local] = x
+                ref = torch.empty_like(pipe.full[c])
+                _all_gather_rows(ref, send, self.group)
+                torch.cuda.synchronize(dev)
+                for q in range(pipe.world):
+                    lo = q * pipe.per
+                    if pipe.halo is None or q == pipe.rank:
+                        same = torch.equal(pipe.full[c][lo:lo + pipe.per], ref[lo:lo + pipe.per])
+                    else:
+                        sel = pipe.halo[q].to(torch.int64) + lo
+                        same = bool(sel.numel() == 0 or torch.equal(pipe.full[c][sel], ref[sel]))
+                    if not same and not bad:
+                        bad = 1000 * trial + c + 1       # (trial, chunk) of the first difference this rank saw
+                del ref, send
+        try:
+            pipe.ipc.check()
+        except Exception:  # noqa: BLE001 -- a wait that gave up is a mismatch too (the blocks are NaN-poisoned)
+            bad = bad or 9999
+        verdict = torch.tensor([bad], dtype=torch.int64, device=dev)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MAX, group=self.group)
+        v = int(verdict.item())
+        if v == 0:
+            return None
+        return "a wait of the exchange gave up" if v == 9999 else f"gathered bytes differ: test pattern {v // 1000}, feature chunk {v % 1000 - 1}"
 
     def check(self) -> None:
         """Raise if any exchange of any pipeline ever timed out (see :meth:`PipelinedHopAggregation.check`); the step

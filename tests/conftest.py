@@ -12,6 +12,7 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "time_cap(seconds): wall-clock cap of this test (default 420 s; tests/conftest.py)")
     # property-based sweeps draw the SAME examples on every run (a suite that is green today is green tomorrow); explore with
     # fresh draws by setting H2GCN_FUZZ_RANDOM=1 (and H2GCN_FUZZ_EXAMPLES=<n>, --hypothesis-seed=<s>): round 4 ran 4 500 / 24 000
     # random examples of the SpMM / metrics sweeps that way
@@ -25,14 +26,54 @@ def pytest_configure(config):
         pass
 
 
+# Order of the -m gpu suite (the driver runs it with -x): the parity tests proper come FIRST -- the aggregation kernel against the
+# oracle, the property sweeps, the ring kernels, the model glue -- and the multi-process tests (several ranks sharing the box's one
+# GPU, rendezvous ports, RCCL's watchdog) LAST, so that nothing that can go wrong in a launcher costs a parity test its run.
+# Inside test_multirank_gpu.py the row-partition bit-equality tests run before the bench / supervisor failure-injection tests.
+_FILE_RANK = ["test_spmm_gpu", "test_fullsize_parity_gpu", "test_fuzz_gpu", "test_rings_gpu", "test_model_gpu", "test_entrypoints",
+              "test_optim_gpu", "test_metrics_gpu", "test_classifier_gpu", "test_multirank_gpu"]
+_DEFAULT_CAP_S = 420
+
+
+def _order_key(item):
+    stem = Path(str(item.fspath)).stem
+    rank = _FILE_RANK.index(stem) if stem in _FILE_RANK else len(_FILE_RANK) - 1      # unknown files: before the multi-process file
+    late = 1 if (stem == "test_multirank_gpu" and (item.name.startswith("test_bench_") or item.name.startswith("test_rccl_"))) else 0
+    return (rank, late)
+
+
 def pytest_collection_modifyitems(config, items):
-    """No single test may eat the suite's time limit: a cap per test (pytest-timeout, when the plugin is there) turns a hang into
-    ONE failing test instead of a suite that never reports (the slowest legitimate test, a real RCCL watchdog abort, takes ~95 s)."""
-    if not config.pluginmanager.hasplugin("timeout"):
+    """Parity first, launchers last (see _FILE_RANK); the sort is stable, so the order inside a file is the file's own."""
+    items.sort(key=_order_key)
+
+
+def _cap_seconds(item):
+    m = item.get_closest_marker("time_cap")
+    return int(m.args[0]) if m and m.args else _DEFAULT_CAP_S
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_call(item):
+    """No single test may eat the suite's time limit: a cap per test (SIGALRM, no plug-in needed; `@pytest.mark.time_cap(s)` sets
+    another one) turns a hang into ONE failing test instead of a suite that never reports.  Child processes a test started are
+    reaped by the test's own `finally` blocks (the exception below unwinds through them)."""
+    import signal
+
+    cap = _cap_seconds(item)
+    if cap <= 0 or not hasattr(signal, "SIGALRM"):
+        yield
         return
-    for item in items:
-        if item.get_closest_marker("timeout") is None:
-            item.add_marker(pytest.mark.timeout(420))
+
+    def on_alarm(signum, frame):
+        raise TimeoutError(f"{item.nodeid}: exceeded its cap of {cap} s (tests/conftest.py)")
+
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    signal.alarm(cap)
+    try:
+        yield
+    finally:
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, old)
 
 
 @pytest.fixture(scope="session", autouse=True)

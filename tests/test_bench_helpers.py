@@ -66,6 +66,13 @@ def test_rccl_log_summary(tmp_path, monkeypatch):
     monkeypatch.setenv("NCCL_DEBUG", "VERSION")          # what the GPU image exports: too quiet, and it prints to stdout
     enable_rccl_debug_log(str(tmp_path))
     assert os.environ["NCCL_DEBUG"] == "INFO" and os.environ["NCCL_DEBUG_FILE"].startswith(str(tmp_path))
+    # a measuring run logs communicator set-up only; the per-collective TUNING lines (file I/O on the launching thread inside a
+    # timed step) are for the stand-alone first-contact run / on request
+    assert os.environ["NCCL_DEBUG_SUBSYS"] == "INIT,GRAPH"
+    monkeypatch.delenv("NCCL_DEBUG_SUBSYS")
+    monkeypatch.setenv("NCCL_DEBUG", "WARN")             # a level the caller chose on purpose is kept
+    enable_rccl_debug_log(str(tmp_path), tuning=True)
+    assert os.environ["NCCL_DEBUG_SUBSYS"] == "INIT,GRAPH,TUNING" and os.environ["NCCL_DEBUG"] == "WARN"
     assert summarize_rccl_log(str(tmp_path)) == []                       # no file yet
     (tmp_path / f"rccl.{socket.gethostname()}.{os.getpid()}").write_text(RCCL_LOG)
     got = summarize_rccl_log(str(tmp_path))

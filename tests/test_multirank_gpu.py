@@ -338,6 +338,47 @@ def test_row_partitioned_propagation_reuse_is_invisible(tmp_path):
 
 
 
+def test_ipc_exchange_is_verified_against_an_all_gather_and_falls_back(tmp_path):
+    """The run-time gate of the IPC exchange (csrc/exchange.hip, "Visibility across devices").  What ranks that
+    share ONE GPU cannot test -- that a remote device sees the staged slot -- is checked by the run itself: the first IPC pipeline of
+    a row-partitioned run gathers two test patterns through the IPC exchange and through the process group's all-gather and
+    compares.  H2GCN_XCHG_INJECT_STALE=1 makes the library stop updating its send slot from the second step on (the peers pull
+    stale bytes): the run must notice, say so, continue on the `allgather` exchange and end exactly where an `allgather` run ends.
+    With the gate switched off the same injection does corrupt the training -- the gate is what stands between the two."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import load_planetoid_golden
+    from test_entrypoints import _export_fixture
+
+    data_dir = tmp_path / "data"
+    _export_fixture(load_planetoid_golden("cora"), data_dir, "ind.cora")
+    configs = {"allgather": ("allgather", {}), "ipc_clean": ("ipc_kernel", {}), "ipc_stale_gated": ("ipc_kernel", {"H2GCN_XCHG_INJECT_STALE": "1"}),
+               "ipc_stale_ungated": ("ipc_kernel", {"H2GCN_XCHG_INJECT_STALE": "1", "H2GCN_XCHG_VERIFY": "0"})}
+    results, logs = {}, {}
+    for name, (exchange, more_env) in configs.items():
+        port = _free_port()
+        out_file = tmp_path / f"stats_{name}.json"
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, H2GCN_ROOT=str(ROOT), DATA_DIR=str(data_dir), OUT_FILE=str(out_file), EPOCHS="6", EXTRA="--no_propagation_reuse",
+                       NETWORK="M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", H2GCN_EXCHANGE=exchange, RANK=str(rank), LOCAL_RANK=str(rank),
+                       WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1",
+                       PYTHONWARNINGS="always", **more_env)
+            env.pop("PROP_DUMP", None)
+            procs.append(subprocess.Popen([sys.executable, "-c", TRAIN_WORKER_TIMED], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        results[name], logs[name] = json.loads(out_file.read_text()), outs
+    said = "does not reproduce an all-gather"
+    assert not any(said in o for o in logs["ipc_clean"]) and not any(said in o for o in logs["allgather"])
+    assert all(said in o and "gathered bytes differ: test pattern 2" in o for o in logs["ipc_stale_gated"]), logs["ipc_stale_gated"]   # every rank
+    keys = ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_accuracy")
+    for k in keys:
+        assert results["ipc_clean"][k] == results["allgather"][k], (k, results["ipc_clean"][k], results["allgather"][k])
+        assert results["ipc_stale_gated"][k] == results["allgather"][k], (k, results["ipc_stale_gated"][k], results["allgather"][k])
+    # without the gate the stale slot reaches the training
+    assert any(not (results["ipc_stale_ungated"][k] == results["allgather"][k]) for k in keys), results["ipc_stale_ungated"]
+
+
 def test_row_partitioned_training_replays_as_hipgraph(tmp_path):
     """Row-partitioned training with every exchange on the library's copy-kernel IPC path (H2GCN_EXCHANGE=ipc_kernel):
     the train and evaluation steps -- all-gathers, reduce-scatters, the gradient all-reduce -- are captured into hipGraphs
@@ -492,6 +533,22 @@ dist.barrier(); dist.destroy_process_group()
             procs.append(subprocess.Popen([sys.executable, "-c", worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=300)[0].decode() for p in procs]
         assert all(p.returncode == 0 for p in procs) and all("TIMEOUT_OK" in o for o in outs), "\n".join(outs)
+
+
+def _one_retry(fn):
+    """The two tests that wait for a real time-out to fire (a hung rank; RCCL's watchdog) depend on a rendezvous port staying free
+    and on a watchdog thread's schedule: one retry, with a warning that says so, before the failure counts."""
+    import functools
+    import warnings
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        try:
+            return fn(*a, **k)
+        except (AssertionError, subprocess.TimeoutExpired) as e:
+            warnings.warn(f"{fn.__name__}: first try failed ({str(e)[:300]}); retrying once")
+            return fn(*a, **k)
+    return wrapper
 
 
 def _reap(procs):
@@ -767,16 +824,25 @@ def test_bench_rank_aborting_in_every_attempt_is_one_error_line(tmp_path):
     assert {e["calibration"] for e in timed} == {"allgather/2", "ipc_kernel/2"}      # rung 2 runs the library's own exchange
 
 
+@_one_retry
 def test_bench_survives_a_rank_that_hangs_inside_exchange_only(tmp_path):
-    """A rank that stops responding (never returns from the diagnostics' exchange_only stage) instead of dying: its peers
-    block in the collective; the attempt's wall-clock budget takes all of them down and the relaunch delivers the line."""
+    """A rank that stops responding (never returns from the diagnostics' exchange_only stage) instead of dying.  Its peer either
+    sits in the collective until the attempt's budget takes every rank down, or leaves on its own when the exchange's bounded wait
+    gives up -- both are the design; which one wins is a race this test does not referee (the budget path alone is pinned with
+    scripted workers in tests/test_bench_supervisor.py::test_a_rank_that_hangs_is_bounded_by_the_attempt_budget).  What is asserted
+    are the EVENTS: the first attempt failed AFTER its calibration had completed, rank 1 did not end by itself, the relaunch
+    delivered the line with the bits of the single-GPU result."""
     lines, err, rcs = _run_supervised(2, ["--chunks", "2"], {"H2GCN_BENCH_HANG_RANK": "1", "H2GCN_BENCH_FAIL_STAGE": "exchange_only",
-                                                             "H2GCN_BENCH_ATTEMPT_BUDGET_S": "60", "H2GCN_DIST_TIMEOUT_S": "900"})
+                                                             "H2GCN_BENCH_ATTEMPT_BUDGET_S": "40", "H2GCN_DIST_TIMEOUT_S": "900"})
     assert len(lines) == 1 and rcs == [0, 0], (lines, err[-3000:])
     out = json.loads(lines[0])
     assert out["value"] > 0 and out["config"]["checksum_matches_n1"] is True
-    first = out["config"]["diagnostics"]["first_attempt"]
-    assert "budget" in first["first_failure"] and len([e for e in first["calibration"] if "ms_per_step" in e]) >= 2
+    diag = out["config"]["diagnostics"]
+    first = diag["first_attempt"]
+    assert first["attempt"] == 0 and first["first_failure"], first
+    assert first["ranks"]["1"] != "ok", first                                       # the hung rank was taken down, it never finished
+    assert len([e for e in first["calibration"] if "ms_per_step" in e]) >= 2        # the stage before the injected one is on record
+    assert diag["attempts"][0]["result"] != "ok" and diag["attempts"][-1]["result"] == "ok", diag["attempts"]
 
 
 def test_rccl_itself_with_three_ranks_on_one_gpu():
@@ -808,6 +874,7 @@ def test_bench_two_ranks_over_rccl(tmp_path):
     _keep("bench_shared_gpu_arxiv_n2_rccl.json", out)
 
 
+@_one_retry
 def test_bench_survives_a_real_rccl_watchdog_abort(tmp_path):
     """The failure the supervisor exists for, for real: rank 1 stops responding, rank 0 sits in an RCCL collective, the
     ProcessGroupNCCL watchdog gives up after H2GCN_DIST_TIMEOUT_S and takes rank 0's process down -- not a Python exception.

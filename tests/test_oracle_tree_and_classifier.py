@@ -142,3 +142,59 @@ def test_keras_rmsprop_by_hand():
     KerasRMSprop([w], lr=0.01).step()
     assert np.allclose(w.detach().numpy(), -0.01 * g / np.sqrt(0.1 * g * g + 1e-7), rtol=1e-12)
     assert abs(w[2].item() / -0.01 - 1e-5 / np.sqrt(1e-11 + 1e-7)) < 1e-9        # 0.0316: the epsilon floor, not 1 / sqrt(0.1) = 3.16
+
+
+def test_threaded_tree_oracle_has_the_bits_of_the_serial_one_and_the_checksum_helpers_count_right():
+    """oracle_spmm_tree_f32_mt (rows spread over OpenMP threads, what the full-size GPU checks run) == oracle_spmm_tree_f32 bit
+    for bit, forward and adjoint, long segments included; the whole-array helpers agree with numpy."""
+    import scipy.sparse as sp
+    from oracle import fullsize as fs
+    from oracle import gcn_layer as og
+
+    rng = np.random.default_rng(11)
+    n, d = 900, 40
+    hops = []
+    for k, dens in enumerate((0.01, 0.08)):
+        m = sp.random(n, n, dens, format="lil", random_state=k, dtype=np.float32)
+        m[5, :700] = 1.0                                   # a long segment (>= 256): the 4-"wave" branch of the tree
+        m = sp.csr_matrix(m)
+        m.data[:] = rng.uniform(-1, 1, len(m.data)).astype(np.float32)
+        m.sort_indices()
+        hops.append(m)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    parts = [og._csr_parts(m) for m in hops]
+    y0, y1 = og.gcn_layer_tree(hops, x), fs.gcn_layer_tree_mt(parts, x)
+    assert np.array_equal(y0, y1)
+    assert np.array_equal(og.gcn_layer_c(hops, x), fs.gcn_layer_seq_mt(parts, x))
+    dy = rng.uniform(-1, 1, (n, 2, d)).astype(np.float32)
+    t_parts = []
+    for m in hops:
+        t = m.T.tocsr()
+        t.sort_indices()
+        t_parts.append(og._csr_parts(t))
+    assert np.array_equal(og.gcn_layer_grad_tree(hops, dy, n), fs.gcn_layer_grad_tree_mt(t_parts, dy))
+    assert fs.bits_checksum(y0) == int(y0.view(np.int32).astype(np.int64).sum())
+    assert fs.count_bit_mismatches(y0, y1) == (0, -1)
+    y2 = y1.copy()
+    y2.reshape(-1)[[77, 5000]] += np.float32(1e-3)
+    y2.reshape(-1)[9] = -y2.reshape(-1)[9] if y2.reshape(-1)[9] != 0 else np.float32(-0.0)
+    assert fs.count_bit_mismatches(y0, y2) == (3, 9)
+    assert abs(fs.max_abs_diff(y0, y2) - float(np.abs(y0.astype(np.float64) - y2).max())) < 1e-12
+    y2.reshape(-1)[3] = np.nan
+    assert fs.max_abs_diff(y0, y2) == float("inf")
+
+
+def test_bench_checksum_constants_come_from_the_oracle():
+    """bench.py's N1_CHECKSUMS (what `checksum_matches_n1` compares with) is the ORACLE's checksum of Y -- recomputed here on the
+    CPU for BASELINE configs[2] (the arxiv shape: a second; the products constant is re-derived the same way by `python -m
+    oracle.fullsize products`, ~30 s on 8 cores, and asserted on the GPU box in tests/test_fullsize_parity_gpu.py)."""
+    import sys
+    from pathlib import Path
+    from oracle import fullsize as fs
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+
+    ck, nnz = fs.oracle_checksum("arxiv", block_rows=60_000)       # three row blocks: the sum does not depend on the blocking
+    assert ck == bench.N1_CHECKSUMS[("arxiv", 128)]
+    assert nnz == [1203951, 1205200]

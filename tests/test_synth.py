@@ -66,3 +66,26 @@ def test_mixed_class_shapes_are_what_their_names_say():
     assert 0.55 < (bi <= 16).mean() < 0.65 and 0.3 < bi[bi <= 16].sum() / bi.sum() < 0.37 and 17.0 < bi.mean() < 18.5
     assert np.array_equal(bi, synth.hop_degrees(synth.SHAPES["bimodal"])[0])           # identical on every rank
     assert np.array_equal(synth.hop_degrees(synth.SHAPES["products"])[0], synth.synth_degrees(2_400_000, 120_000_000, synth.SEED_A1, 2_400_000))
+
+
+def test_c_restatement_of_the_generator_is_bit_identical():
+    """oracle/spmm_oracle.c restates the generator so that the full-size GPU checks can rebuild EVERY row of the BASELINE shapes on
+    the host in seconds (tests/test_fullsize_parity_gpu.py); pinned here against the numpy definition: whole matrices, row blocks,
+    rows that collide (duplicates removed), empty rows, both degree families, features at arbitrary row windows."""
+    from oracle import fullsize as fs
+
+    assert fs.stream_key(synth.SEED_A1) == synth._stream_key(synth.SEED_A1) and fs.stream_key(7) == synth._stream_key(7)
+    for n, nnz, seed, family in ((3000, 60000, 124, "pareto"), (500, 40000, 9, "pareto"), (4000, 30000, 5, "lognormal")):
+        deg = synth.synth_degrees(n, nnz, seed, n) if family == "pareto" else synth.synth_degrees_lognormal(n, nnz, seed, n)
+        assert (deg == 0).any()
+        for r0, r1 in ((0, n), (17, n // 2), (n - 5, n), (40, 41)):
+            want = synth.synth_hop_rows_np(deg, n, seed, r0, r1)
+            got = fs.synth_hop_rows_c(deg, n, seed, r0, r1)
+            for a, b in zip(want, got):
+                assert a.dtype == b.dtype and np.array_equal(a, b), (n, family, r0, r1)
+        assert len(want[1]) <= int(deg[40:41].sum())
+    dense = np.full(50, 45, dtype=np.int64)                 # 45 draws out of 50 columns: collisions in every row
+    a, b = synth.synth_hop_rows_np(dense, 50, 3, 0, 50), fs.synth_hop_rows_c(dense, 50, 3, 0, 50)
+    assert len(a[1]) < 45 * 50 and all(np.array_equal(p, q) for p, q in zip(a, b))
+    for d, r0, r1 in ((128, 0, 700), (67, 5, 4000), (1, 10 ** 9, 10 ** 9 + 50)):
+        assert np.array_equal(synth.synth_features_np(d, synth.SEED_X, r0, r1), fs.synth_features_c(d, synth.SEED_X, r0, r1))

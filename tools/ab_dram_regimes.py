@@ -55,10 +55,11 @@ class Lib:
         if st < 0:
             raise RuntimeError(f"{self.name}: {self.L.h2gcn_last_error().decode()} (status {st})")
 
-    def create(self, csr, n_cols):
+    def create(self, csr, n_cols, transpose=True, variant=0, rows_per_wave=0, slice_cols=0):
         n_rows = csr[0][0].numel() - 1
         arr = C.c_void_p * len(csr)
-        opts = PlanOpts(struct_size=C.sizeof(PlanOpts), flags=PLAN_BUILD_TRANSPOSE)
+        opts = PlanOpts(struct_size=C.sizeof(PlanOpts), flags=PLAN_BUILD_TRANSPOSE if transpose else 0, variant=variant,
+                        rows_per_wave=rows_per_wave, slice_cols=slice_cols)
         stream = torch.cuda.current_stream().cuda_stream
         self.check(self.L.h2gcn_plan_create(len(csr), n_rows, n_cols, arr(*[c[0].data_ptr() for c in csr]), arr(*[c[1].data_ptr() for c in csr]),
                                             arr(*[c[2].data_ptr() for c in csr]), C.byref(opts), C.c_void_p(stream), C.byref(self.plan)))
@@ -69,28 +70,28 @@ class Lib:
             self.plan = C.c_void_p()
         self.ws = {}
 
-    def _opts(self, adjoint, src, ld_row, ld_hop, d):
+    def _opts(self, adjoint, src, ld_row, ld_hop, d, mask=0):
         """Same scratch rule as HopPlan.spmm / spmm_t (the library asks for a slice-major copy of some sources)."""
-        key = (adjoint, d)
+        key = (adjoint, d, mask)
         if key not in self.ws:
-            nbytes = int(self.L.h2gcn_spmm_workspace_bytes(self.plan, 0, adjoint, C.c_void_p(src.data_ptr()), ld_row, ld_hop, d))
+            nbytes = int(self.L.h2gcn_spmm_workspace_bytes(self.plan, mask, adjoint, C.c_void_p(src.data_ptr()), ld_row, ld_hop, d))
             self.ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=src.device) if nbytes else None
         ws = self.ws[key]
         if ws is None:
             return None
         return LaunchOpts(struct_size=C.sizeof(LaunchOpts), flags=0, workspace=ws.data_ptr(), workspace_bytes=ws.numel(), bias=None)
 
-    def forward(self, x, y):
+    def forward(self, x, y, mask=0):
         d = x.shape[1]
-        o = self._opts(0, x, x.stride(0), 0, d)
-        self.check(self.L.h2gcn_spmm_hops_opts_f32(self.plan, 0, C.c_void_p(x.data_ptr()), x.stride(0), d, C.c_void_p(y.data_ptr()), y.stride(0),
+        o = self._opts(0, x, x.stride(0), 0, d, mask)
+        self.check(self.L.h2gcn_spmm_hops_opts_f32(self.plan, mask, C.c_void_p(x.data_ptr()), x.stride(0), d, C.c_void_p(y.data_ptr()), y.stride(0),
                                                    y.stride(1), C.byref(o) if o is not None else None,
                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
-    def adjoint(self, dy, dx):
+    def adjoint(self, dy, dx, mask=0):
         d = dy.shape[2]
-        o = self._opts(1, dy, dy.stride(0), dy.stride(1), d)
-        self.check(self.L.h2gcn_spmm_hops_T_opts_f32(self.plan, 0, C.c_void_p(dy.data_ptr()), dy.stride(0), dy.stride(1), d, C.c_void_p(dx.data_ptr()),
+        o = self._opts(1, dy, dy.stride(0), dy.stride(1), d, mask)
+        self.check(self.L.h2gcn_spmm_hops_T_opts_f32(self.plan, mask, C.c_void_p(dy.data_ptr()), dy.stride(0), dy.stride(1), d, C.c_void_p(dx.data_ptr()),
                                                      dx.stride(0), C.byref(o) if o is not None else None,
                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
@@ -109,6 +110,85 @@ def timed(fn, warm, launches):
     return [s.elapsed_time(e) for s, e in evs]
 
 
+def forward_vs_adjoint(a):
+    """--matrix (round 6): why is the DRAM-resident forward 15 points below its own adjoint?  One process, one set
+    of operands, every configuration a (library, plan options, direction, hop mask) tuple taking turns per round:
+      F2 / F1  forward, both hops / hop 0 only          A2 / A1  adjoint, both hops / hop 0 only
+      *_nostore  the same launches of a build that computes every sum but does not issue the output stream (-DH2GCN_AB_NO_STORES)
+      F2 v2 / rpwN   forward with the cross-segment index prefetch (variant 2) / N rows per wave
+      F2 / A2 of builds with other launch bounds / load-batch depths (w7b8, w6b4, w7b4 = waves per SIMD, deepest batch)
+    Rates are quoted on each launch's OWN algorithmic bytes (one-hop launches: that hop's nonzeros + its share of the output)."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    libs = dict(spec.split("=", 1) for spec in a.libs)
+    shape = a.shapes[0]
+    cfg = synth.SHAPES[shape]
+    n, d = cfg["n"], cfg["d"]
+    seeds = (synth.SEED_A1, synth.SEED_A2)
+    degs = synth.hop_degrees(cfg, seeds)
+    csr = [synth.synth_hop_rows(degs[k], n, seeds[k], 0, n, dev) for k in range(2)]
+    x = synth.synth_features(d, synth.SEED_X, 0, n, dev)
+    dy = synth.synth_features(2 * d, 77, 0, n, dev).view(n, 2, d)
+    y = torch.empty((n, 2, d), dtype=torch.float32, device=dev)
+    y1 = torch.empty((n, 1, d), dtype=torch.float32, device=dev)
+    dx = torch.empty((n, d), dtype=torch.float32, device=dev)
+    nnz = [int(c[0][-1]) for c in csr]
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+    def b_alg(hops, out_hops):
+        return sum(nnz[k] * (8 + 4 * d) + (n + 1) * 8 for k in hops) + n * out_hops * d * 4
+
+    plans = {}
+
+    def plan(lib, transpose, **kw):
+        key = (lib, transpose, tuple(sorted(kw.items())))
+        if key not in plans:
+            lb = Lib(lib, libs[lib])
+            lb.create(csr, n, transpose=transpose, **kw)
+            plans[key] = lb
+        return plans[key]
+
+    base = a.baseline or next(iter(libs))
+    configs = []   # (label, callable, algorithmic bytes)
+    pb = plan(base, True)
+    configs.append(("F2 forward, hops 0+1", lambda: pb.forward(x, y), b_alg((0, 1), 2)))
+    configs.append(("F1 forward, hop 0 only", lambda: pb.forward(x, y1, mask=1), b_alg((0,), 1)))
+    configs.append(("A2 adjoint, hops 0+1", lambda: pb.adjoint(dy, dx), b_alg((0, 1), 1)))
+    configs.append(("A1 adjoint, hop 0 only", lambda: pb.adjoint(dy, dx, mask=1), b_alg((0,), 1)))
+    if "nostore" in libs:
+        pn = plan("nostore", True)
+        configs.append(("F2 nostore (sums computed, no output stream)", lambda: pn.forward(x, y), b_alg((0, 1), 0)))
+        configs.append(("F1 nostore", lambda: pn.forward(x, y1, mask=1), b_alg((0,), 0)))
+        configs.append(("A2 nostore", lambda: pn.adjoint(dy, dx), b_alg((0, 1), 0)))
+    for label, kw in (("F2 variant 2 (index prefetch across segments)", dict(variant=2)), ("F2 rows_per_wave 1", dict(rows_per_wave=1)),
+                      ("F2 rows_per_wave 2", dict(rows_per_wave=2)), ("F2 rows_per_wave 7", dict(rows_per_wave=7)),
+                      ("F2 slice 128", dict(slice_cols=128))):
+        pv = plan(base, False, **kw)
+        configs.append((label, (lambda q: (lambda: q.forward(x, y)))(pv), b_alg((0, 1), 2)))
+    for name in libs:
+        if name in (base, "nostore"):
+            continue
+        pl = plan(name, True)
+        configs.append((f"F2 build {name}", (lambda q: (lambda: q.forward(x, y)))(pl), b_alg((0, 1), 2)))
+        configs.append((f"A2 build {name}", (lambda q: (lambda: q.adjoint(dy, dx)))(pl), b_alg((0, 1), 1)))
+    torch.cuda.synchronize()
+    print(f"# {shape}: |V| = {n}, nnz = {nnz}, d = {d}; X = {n * d * 4 / 1e9:.2f} GB; device {torch.cuda.get_device_name(0)}")
+    print(f"# libraries: {libs}; baseline build: {base}")
+    print(f"# {a.rounds} rounds x [2 warm-up + {a.launches} timed launches] per configuration, configurations take turns; median launch per round")
+    per = {c[0]: [] for c in configs}
+    for r in range(a.rounds):
+        for label, fn, _ in configs:
+            per[label].append(statistics.median(timed(fn, 2, a.launches)))
+    out = {}
+    for label, _, b in configs:
+        v = per[label]
+        med = statistics.median(v)
+        out[label] = {"median_ms": med, "min_ms": min(v), "max_ms": max(v), "algorithmic_GB": b / 1e9, "GBps": b / med / 1e6, "frac": b / med / 1e6 / 8000}
+        print(f"{label:<52} {med:9.3f} ms  [{min(v):8.3f} .. {max(v):8.3f}]   {b / 1e9:8.2f} GB  {b / med / 1e6:7.0f} GB/s  {b / med / 1e6 / 8000:.3f} of 8 TB/s")
+    print("\n" + json.dumps({"matrix": out}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--libs", nargs="+", required=True, help="name=path ...")
@@ -116,7 +196,10 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--launches", type=int, default=10)
     ap.add_argument("--baseline", default=None, help="library the relative differences are quoted against (default: the second)")
+    ap.add_argument("--matrix", action="store_true", help="forward-vs-adjoint matrix on the first of --shapes (see forward_vs_adjoint)")
     a = ap.parse_args()
+    if a.matrix:
+        return forward_vs_adjoint(a)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     libs = [Lib(*spec.split("=", 1)) for spec in a.libs]

@@ -116,7 +116,11 @@ int point(size_t table_mib, int row_bytes) {
     CHECK(hipFree(table)); CHECK(hipFree(out));
     const double c = run_copy(2ull << 30);
     const double r = run_read(4ull << 30);
-    printf("{\"table_MiB\": %zu, \"row_bytes\": %d, \"gather_GBps\": %.1f, \"copy_GBps\": %.1f, \"stream_read_GBps\": %.1f, "
+    // what the box says about its memory system ("confirm on the box"): hipDeviceProp_t's memory clock and bus width
+    hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+    printf("{\"memory_clock_khz\": %d, \"memory_bus_width_bits\": %d, \"device_name\": \"%s\", \"gcn_arch\": \"%s\", \"total_global_mem_GiB\": %.1f, ",
+           prop.memoryClockRate, prop.memoryBusWidth, prop.name, prop.gcnArchName, (double)prop.totalGlobalMem / (double)(1ull << 30));
+    printf("\"table_MiB\": %zu, \"row_bytes\": %d, \"gather_GBps\": %.1f, \"copy_GBps\": %.1f, \"stream_read_GBps\": %.1f, "
            "\"what\": \"tools/gather_probe: random row gathers out of a table of this size (8 x 16-B loads in flight per lane); "
            "copy = nontemporal stream copy of 2 GiB, read+write bytes; stream_read = read-only pass over 4 GiB\"}\n", table_mib, row_bytes, g, c, r);
     return 0;
