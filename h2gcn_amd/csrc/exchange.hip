@@ -46,11 +46,12 @@
 //   (4) The pulled bytes land in `full` (local memory) and reach the SpMM through a stream / event / graph edge: (1) again.
 //   With every rank on ONE device (the test box) all of this traffic has the same home and the same L2s, so (1) and (3) are
 //   exercised but can never FAIL there: a missing write-back or invalidate would be invisible.  That is the one property of
-//   this file no test on this box can pin.  It is therefore gated at run time instead: the first time a training run builds an
-//   IPC pipeline, partition.ShardedHops gathers two test patterns through it AND through ncclAllGather and compares the
-//   results on every rank (one collective each, outside any capture); a mismatch -- H2GCN_XCHG_INJECT_STALE=1 fakes one by
-//   not updating the slot from the second step on -- switches the run to the `allgather` exchange with a warning.  bench.py
-//   gates every IPC candidate the same way (against the regenerated embedding) before it is timed.
+//   this file no test on this box can pin.  It is therefore gated at run time instead: setting up a row-partitioned run
+//   (partition.ShardedHops) sends FOUR test patterns -- both slots of a channel, each used twice: the re-use is where a stale
+//   line could be served -- through an L2-sized IPC exchange of the requested mode AND through ncclAllGather and compares the
+//   results on every rank (eager, before anything decides on hipGraph replay); a mismatch -- H2GCN_XCHG_INJECT_STALE=1 fakes one
+//   by not updating the slot from the second step on -- switches the run to the `allgather` exchange with a warning.  bench.py
+//   gates every IPC candidate the same way (against the regenerated embedding, two inputs) before it is timed.
 //
 // Deadlock freedom: signal(q) is enqueued before any wait(q) of the same rank, and everything enqueued before
 // signal(q) depends only on signals < q of the peers -- induction over (step, channel) order, independent of how

@@ -1091,6 +1091,43 @@ __global__ __launch_bounds__(kBlock, EXACT ? (LISTS ? (FB == 4 ? H2GCN_SHORT_FB4
         return;
     }
 
+#ifdef H2GCN_AB_STORE_BEHIND_FETCH
+    // A/B builds only (profiles/r06_ab_forward_vs_adjoint_x6.txt): the forward wave walk with a segment's store issued BEHIND the
+    // next segment's index fetch instead of in front of it.  The wave waits for everything outstanding before it fetches a
+    // segment's indices (the compiler's vmcnt(0) at the loop head), so a store issued right after the fold is a write round trip
+    // the wave sits out; issued after the next index fetch it completes under that fetch and the first gather batch.
+    if constexpr (EXACT && !SUM && !EPI) {
+        float held[VEC];
+        int64_t held_off = 0;
+        bool held_valid = false;
+        for (int r = 0; r < rows_here; ++r) {
+            const int64_t row = row0 + r;
+            for (int s = 0; s < n_sel; ++s) {
+                const int l0 = s * (rpw + 1) + r;
+                const int64_t sb = seg_bound(l0), se = seg_bound(l0 + 1);
+                if (se - sb >= p.long_threshold) continue;  // a workgroup of the long path owns it
+                const HopCsr& h = p.hop[s];
+                int c;
+                float v;
+                load_chunk(h.colidx, h.vals, sb, se, lane, c, v);
+                if (held_valid) {
+                    if (g == 0) store_out<VEC, EPI>(p, p.dst + held_off, lcol, ecol, held);
+                    held_valid = false;
+                }
+                float acc[NP][VEC];
+                zero_acc<VEC, NP>(acc);
+                const GatherAddr<OFF32> addr{reinterpret_cast<const char*>(p.src + p.src_hop_off[s] + src_col_begin - kBias), lane_off0, (off_t)(p.ld_src * 4)};
+                accumulate_segment_prefetched<VEC, LPR, OFF32, kMainB>(h.colidx, h.vals, sb, se, c, v, addr, lane, acc);
+                fold_tree<VEC, LPR, NP>(acc, held);
+                held_off = row * p.ld_dst + p.dst_hop_off[s];
+                held_valid = true;
+            }
+        }
+        if (held_valid && g == 0) store_out<VEC, EPI>(p, p.dst + held_off, lcol, ecol, held);
+        return;
+    }
+#endif
+
     for (int r = 0; r < rows_here; ++r) {
         const int64_t row = row0 + r;
         if constexpr (SUM) {

@@ -901,81 +901,67 @@ class ShardedHops:
         self.n_hops, self.n_rows, self.n_cols = plan.n_hops, plan.n_rows, plan.n_cols
         self.partition = partition
         self._pipes = {}
-        self.verify_fallback = None  # why the IPC exchange was replaced by the all-gather (see pipeline), if it was
+        #: why the IPC exchange this run asked for was replaced by the all-gather, if it was (see _ipc_exchange_mismatch)
+        self.verify_fallback = None
         self._small = None          # (IpcExchange, scratch) of all_reduce_small
         self._small_views = {}
+        if (self.exchange.startswith("ipc_") and self.device.type == "cuda" and dist.is_available() and dist.is_initialized()
+                and dist.get_world_size(group) > 1 and os.environ.get("H2GCN_XCHG_VERIFY", "1") != "0"):
+            why = self._ipc_exchange_mismatch()
+            if why is not None:
+                import warnings
+                warnings.warn(f"h2gcn_amd: the IPC exchange ({self.exchange}) does not reproduce an all-gather of the same tensor on this node "
+                              f"({why}); this run uses exchange='allgather' instead (and no hipGraph replay of row-partitioned steps)")
+                self.exchange, self.verify_fallback = "allgather", why
 
     def pipeline(self, d: int) -> "PipelinedHopAggregation":
         if d not in self._pipes:
             chunks = 1
             while chunks * 2 <= self.max_chunks and d % (chunks * 2) == 0 and d // (chunks * 2) >= self.chunk_cols:
                 chunks *= 2
-
-            def build(exchange):
-                return PipelinedHopAggregation(self.plan, self.n_global, d, chunks, self.device, self.group,
-                                               exchange=exchange if self.device.type == "cuda" or not exchange.startswith("ipc_") else "allgather",
-                                               partition=self.partition,
-                                               # training: a rank may legitimately stall for a long time (first-epoch
-                                               # module loads, rank 0 writing a checkpoint) -- two minutes by default
-                                               ipc_timeout_ms=int(os.environ.get("H2GCN_XCHG_TIMEOUT_MS", "120000")))
-
-            pipe = build(self.exchange)
-            if pipe.ipc is not None and pipe.world > 1 and os.environ.get("H2GCN_XCHG_VERIFY", "1") != "0":
-                # the run-time gate of csrc/exchange.hip ("Visibility across devices"): what one shared GPU cannot test is
-                # checked where it matters -- on the node the run is on, before the first real exchange
-                why = self._ipc_exchange_mismatch(pipe)
-                if why is not None:
-                    import warnings
-                    warnings.warn(f"h2gcn_amd: the IPC exchange ({self.exchange}) does not reproduce an all-gather of the same tensor on this "
-                                  f"node ({why}); this run uses exchange='allgather' instead (no hipGraph replay of row-partitioned steps)")
-                    pipe.close()                      # collective: every rank took the same decision (all-reduced verdict)
-                    self.exchange = "allgather"
-                    self.verify_fallback = why
-                    pipe = build("allgather")
-            self._pipes[d] = pipe
+            self._pipes[d] = PipelinedHopAggregation(self.plan, self.n_global, d, chunks, self.device, self.group,
+                                                     exchange=self.exchange if self.device.type == "cuda" or not self.exchange.startswith("ipc_") else "allgather",
+                                                     partition=self.partition,
+                                                     # training: a rank may legitimately stall for a long time (first-epoch
+                                                     # module loads, rank 0 writing a checkpoint) -- two minutes by default
+                                                     ipc_timeout_ms=int(os.environ.get("H2GCN_XCHG_TIMEOUT_MS", "120000")))
         return self._pipes[d]
 
-    def _ipc_exchange_mismatch(self, pipe: "PipelinedHopAggregation") -> Optional[str]:
-        """Collective, eager (never inside a capture): gather TWO different test patterns through the pipeline's IPC exchange (both
-        slot parities; the second must not deliver the first one's bytes) and through the process group's all-gather, compare on
-        every rank, all-reduce the verdict.  None = identical everywhere; otherwise what differed (same string on every rank)."""
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("ShardedHops: the first use of an IPC pipeline must happen outside a hipGraph capture (run a warm-up step)")
-        dev, n_local = self.device, pipe.r1 - pipe.r0
+    def _ipc_exchange_mismatch(self) -> Optional[str]:
+        """The run-time gate of csrc/exchange.hip ("Visibility across devices").  Collective, eager, once per run, BEFORE anything
+        decides on hipGraph replay: FOUR different test patterns (both slot parities, each used twice -- the re-use of a slot is where
+        a reader could be served a stale cached line) go through a small IPC exchange of the mode this run asked for (1 MiB per rank:
+        L2-sized, the most exposed case) and through the process group's all-gather; every rank compares, the verdict is
+        all-reduced.  None = identical everywhere; otherwise what differed (the same string on every rank)."""
+        dev = self.device
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        per, w = 4096, 64
+        xc = IpcExchange(1, per * w * 4, dev, self.group, mode=self.exchange[4:], timeout_ms=int(os.environ.get("H2GCN_XCHG_TIMEOUT_MS", "120000")))
+        full = torch.empty((world * per, w), dtype=torch.float32, device=dev)
+        ref = torch.empty_like(full)
+        rows = torch.arange(rank * per, (rank + 1) * per, device=dev, dtype=torch.int64)[:, None]
+        cols = torch.arange(w, device=dev, dtype=torch.int64)[None, :]
         bad = 0
-        rows = torch.arange(pipe.r0, pipe.r1, device=dev, dtype=torch.int64)[:, None]
-        for trial in (1, 2):
-            for c, w in enumerate(pipe.widths):
-                cols = torch.arange(w, device=dev, dtype=torch.int64)[None, :] + pipe.offsets[c]
-                x = ((rows * 131 + cols * 7 + trial * 1000003) % 65521).to(torch.float32)
-                pipe.ipc.begin(c, x, pipe.full[c], pipe.per, pull=False)
-                pipe.ipc.pull(c, pipe.full[c], pipe.per, halo=pipe.halo)
-                pipe.ipc.end(c)
-                send = torch.zeros((pipe.per, w), dtype=torch.float32, device=dev)
-                send[:n_local] = x
-                ref = torch.empty_like(pipe.full[c])
-                _all_gather_rows(ref, send, self.group)
-                torch.cuda.synchronize(dev)
-                for q in range(pipe.world):
-                    lo = q * pipe.per
-                    if pipe.halo is None or q == pipe.rank:
-                        same = torch.equal(pipe.full[c][lo:lo + pipe.per], ref[lo:lo + pipe.per])
-                    else:
-                        sel = pipe.halo[q].to(torch.int64) + lo
-                        same = bool(sel.numel() == 0 or torch.equal(pipe.full[c][sel], ref[sel]))
-                    if not same and not bad:
-                        bad = 1000 * trial + c + 1       # (trial, chunk) of the first difference this rank saw
-                del ref, send
+        for trial in (1, 2, 3, 4):
+            x = ((rows * 131 + cols * 7 + trial * 1000003) % 65521).to(torch.float32)
+            full.fill_(-1.0)
+            xc.begin(0, x, full, per)
+            xc.end(0)
+            _all_gather_rows(ref, x.contiguous(), self.group)
+            torch.cuda.synchronize(dev)
+            if not bad and not torch.equal(full, ref):
+                bad = trial
         try:
-            pipe.ipc.check()
+            xc.check()
         except Exception:  # noqa: BLE001 -- a wait that gave up is a mismatch too (the blocks are NaN-poisoned)
-            bad = bad or 9999
+            bad = bad or 99
         verdict = torch.tensor([bad], dtype=torch.int64, device=dev)
         dist.all_reduce(verdict, op=dist.ReduceOp.MAX, group=self.group)
+        xc.close()                                       # collective
         v = int(verdict.item())
         if v == 0:
             return None
-        return "a wait of the exchange gave up" if v == 9999 else f"gathered bytes differ: test pattern {v // 1000}, feature chunk {v % 1000 - 1}"
+        return "a wait of the exchange gave up" if v == 99 else f"gathered bytes differ from test pattern {v} on"
 
     def check(self) -> None:
         """Raise if any exchange of any pipeline ever timed out (see :meth:`PipelinedHopAggregation.check`); the step

@@ -340,9 +340,9 @@ def test_row_partitioned_propagation_reuse_is_invisible(tmp_path):
 
 def test_ipc_exchange_is_verified_against_an_all_gather_and_falls_back(tmp_path):
     """The run-time gate of the IPC exchange (csrc/exchange.hip, "Visibility across devices").  What ranks that
-    share ONE GPU cannot test -- that a remote device sees the staged slot -- is checked by the run itself: the first IPC pipeline of
-    a row-partitioned run gathers two test patterns through the IPC exchange and through the process group's all-gather and
-    compares.  H2GCN_XCHG_INJECT_STALE=1 makes the library stop updating its send slot from the second step on (the peers pull
+    share ONE GPU cannot test -- that a remote device sees the staged slot -- is checked by the run itself: setting up a
+    row-partitioned run gathers four test patterns (every send slot used twice) through a small IPC exchange and through the process
+    group's all-gather and compares -- before anything decides on hipGraph replay.  H2GCN_XCHG_INJECT_STALE=1 makes the library stop updating its send slot from the second step on (the peers pull
     stale bytes): the run must notice, say so, continue on the `allgather` exchange and end exactly where an `allgather` run ends.
     With the gate switched off the same injection does corrupt the training -- the gate is what stands between the two."""
     sys.path.insert(0, str(ROOT / "tests"))
@@ -359,7 +359,7 @@ def test_ipc_exchange_is_verified_against_an_all_gather_and_falls_back(tmp_path)
         out_file = tmp_path / f"stats_{name}.json"
         procs = []
         for rank in range(2):
-            env = dict(os.environ, H2GCN_ROOT=str(ROOT), DATA_DIR=str(data_dir), OUT_FILE=str(out_file), EPOCHS="6", EXTRA="--no_propagation_reuse",
+            env = dict(os.environ, H2GCN_ROOT=str(ROOT), DATA_DIR=str(data_dir), OUT_FILE=str(out_file), EPOCHS="4", EXTRA="--no_propagation_reuse",
                        NETWORK="M64-R-T1-G-V-T2-G-V-C1-C2-D0.0-MO", H2GCN_EXCHANGE=exchange, RANK=str(rank), LOCAL_RANK=str(rank),
                        WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), H2GCN_DIST_BACKEND="gloo", H2GCN_SHARE_GPU="1",
                        PYTHONWARNINGS="always", **more_env)
@@ -370,7 +370,7 @@ def test_ipc_exchange_is_verified_against_an_all_gather_and_falls_back(tmp_path)
         results[name], logs[name] = json.loads(out_file.read_text()), outs
     said = "does not reproduce an all-gather"
     assert not any(said in o for o in logs["ipc_clean"]) and not any(said in o for o in logs["allgather"])
-    assert all(said in o and "gathered bytes differ: test pattern 2" in o for o in logs["ipc_stale_gated"]), logs["ipc_stale_gated"]   # every rank
+    assert all(said in o and "gathered bytes differ from test pattern 2 on" in o for o in logs["ipc_stale_gated"]), logs["ipc_stale_gated"]   # every rank
     keys = ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_accuracy")
     for k in keys:
         assert results["ipc_clean"][k] == results["allgather"][k], (k, results["ipc_clean"][k], results["allgather"][k])
@@ -604,14 +604,16 @@ def _keep(name, line):
         (Path(d) / name).write_text(json.dumps(line))
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3])
 def test_bench_multi_rank_branch_runs_and_matches_one_rank(tmp_path, world):
     """bench.py's N > 1 branch end to end (calibration over every exchange x chunking, diagnostics, timed steps,
     JSON line) on the arxiv shape, N ranks sharing the box's GPU; the N-rank result -- whatever chunking the calibration
     picked -- has the same bits as the default 1-rank line (one launch) AND as 1-rank runs with other chunkings / slice
     widths (order-independent checksum of Y): the canonical summation tree, SURVEY.md 8(e) "Determinism"."""
-    # N = 2 and 4: under RCCL itself (all four exchange forms x four chunkings = the full 16-candidate sweep of the 8-GPU run);
-    # N = 3 (170 000 rows / 3: a short last block) over gloo, without its slow stand-in for the grouped send/recv form
+    # N = 2: under RCCL itself (all four exchange forms x four chunkings = the full 16-candidate sweep of the 8-GPU run; 8 ranks run
+    # in test_bench_eight_ranks_on_one_gpu); N = 3 (170 000 rows / 3: a short last block) over gloo, without its slow stand-in for
+    # the grouped send/recv form.  "Matches one rank": the line's checksum equals the ORACLE's for the shape (bench.N1_CHECKSUMS,
+    # recomputed on the CPU in tests/test_oracle_tree_and_classifier.py) -- and so do 1-rank runs with other chunkings / slice widths
     extra_env = {"H2GCN_BENCH_EXCHANGES": "allgather,ipc_engine,ipc_kernel"} if world == 3 else {"H2GCN_DIST_BACKEND": "nccl"}
     out = _run_bench(world, ["--shape", "arxiv", "--steps", "3", "--warmup", "1"], tmp_path, env_extra=extra_env)
     assert out["n_gpus"] == world and out["value"] > 0 and out["roofline"]["kernel_ms_max_over_ranks"] > 0
@@ -626,12 +628,9 @@ def test_bench_multi_rank_branch_runs_and_matches_one_rank(tmp_path, world):
     assert diag["exchange_only_ms"] > 0 and diag["spmm_only_ms"] > 0
     (tmp_path / f"line{world}.json").write_text(json.dumps(out))
     _keep(f"bench_shared_gpu_arxiv_n{world}.json", out)
-    one = _run_bench(1, ["--shape", "arxiv", "--steps", "2", "--warmup", "1"], tmp_path)
-    assert one["config"]["y_checksum"] == out["config"]["y_checksum"]
-    assert one["config"]["nnz_per_hop"] == out["config"]["nnz_per_hop"]
+    assert out["config"]["checksum_matches_n1"] is True and out["config"]["nnz_per_hop"] == [1203951, 1205200]
     if world == 2:
-        for extra in (["--chunks", "2"], ["--chunks", "64+64"], ["--chunks", "4"], ["--chunks", "16+48+64"], ["--slice-cols", "64"],
-                      ["--slice-cols", "128"], ["--slice-cols", "256"]):
+        for extra in (["--chunks", "4"], ["--chunks", "16+48+64"], ["--slice-cols", "64"], ["--slice-cols", "256"]):
             alt = _run_bench(1, ["--shape", "arxiv", "--steps", "1", "--warmup", "1", "--no-adjoint"] + extra, tmp_path)
             assert alt["config"]["y_checksum"] == out["config"]["y_checksum"], extra
 
@@ -696,8 +695,7 @@ def test_bench_eight_ranks_on_one_gpu(tmp_path, backend):
     if backend == "nccl":
         assert any("nranks 8" in ln for ln in out["config"]["diagnostics"]["rccl"]), out["config"]["diagnostics"]["rccl"]
     _keep(f"bench_shared_gpu_arxiv_n8_{backend}.json", out)
-    one = _run_bench(1, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--no-adjoint"], tmp_path)
-    assert one["config"]["y_checksum"] == out["config"]["y_checksum"]
+    assert out["config"]["checksum_matches_n1"] is True           # the oracle's checksum of the shape (bench.N1_CHECKSUMS)
 
 
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
@@ -727,9 +725,7 @@ def test_bench_plain_launch_spawns_its_own_ranks(tmp_path, backend):
     fc = out["config"]["diagnostics"]["first_contact_dry_exchange"]
     assert fc["dry_exchange"] and "ipc_kernel/2" in fc["dry_exchange"], fc
     assert '"dry_exchange"' in r.stderr            # ... and it reached stderr before the big allocations
-    assert out["config"]["checksum_matches_n1"] is True      # against the constant of the single-GPU line embedded in bench.py
-    one = _run_bench(1, ["--shape", "arxiv", "--steps", "2", "--warmup", "1", "--no-adjoint"], tmp_path)
-    assert one["config"]["y_checksum"] == out["config"]["y_checksum"]
+    assert out["config"]["checksum_matches_n1"] is True      # against the oracle's checksum of the shape (bench.N1_CHECKSUMS)
     _keep(f"bench_plain_launch_arxiv_n2_{backend}.json", out)
 
 
@@ -824,27 +820,6 @@ def test_bench_rank_aborting_in_every_attempt_is_one_error_line(tmp_path):
     assert {e["calibration"] for e in timed} == {"allgather/2", "ipc_kernel/2"}      # rung 2 runs the library's own exchange
 
 
-@_one_retry
-def test_bench_survives_a_rank_that_hangs_inside_exchange_only(tmp_path):
-    """A rank that stops responding (never returns from the diagnostics' exchange_only stage) instead of dying.  Its peer either
-    sits in the collective until the attempt's budget takes every rank down, or leaves on its own when the exchange's bounded wait
-    gives up -- both are the design; which one wins is a race this test does not referee (the budget path alone is pinned with
-    scripted workers in tests/test_bench_supervisor.py::test_a_rank_that_hangs_is_bounded_by_the_attempt_budget).  What is asserted
-    are the EVENTS: the first attempt failed AFTER its calibration had completed, rank 1 did not end by itself, the relaunch
-    delivered the line with the bits of the single-GPU result."""
-    lines, err, rcs = _run_supervised(2, ["--chunks", "2"], {"H2GCN_BENCH_HANG_RANK": "1", "H2GCN_BENCH_FAIL_STAGE": "exchange_only",
-                                                             "H2GCN_BENCH_ATTEMPT_BUDGET_S": "40", "H2GCN_DIST_TIMEOUT_S": "900"})
-    assert len(lines) == 1 and rcs == [0, 0], (lines, err[-3000:])
-    out = json.loads(lines[0])
-    assert out["value"] > 0 and out["config"]["checksum_matches_n1"] is True
-    diag = out["config"]["diagnostics"]
-    first = diag["first_attempt"]
-    assert first["attempt"] == 0 and first["first_failure"], first
-    assert first["ranks"]["1"] != "ok", first                                       # the hung rank was taken down, it never finished
-    assert len([e for e in first["calibration"] if "ms_per_step" in e]) >= 2        # the stage before the injected one is on record
-    assert diag["attempts"][0]["result"] != "ok" and diag["attempts"][-1]["result"] == "ok", diag["attempts"]
-
-
 def test_rccl_itself_with_three_ranks_on_one_gpu():
     """RCCL with world size 3 on the box's one GPU (a NCCL_HOSTID per rank; NET/Socket transport): all_gather_into_tensor,
     all_reduce, the grouped isend/irecv all-to-all form, reduce_scatter_tensor and barrier deliver the right bytes."""
@@ -876,11 +851,18 @@ def test_bench_two_ranks_over_rccl(tmp_path):
 
 @_one_retry
 def test_bench_survives_a_real_rccl_watchdog_abort(tmp_path):
-    """The failure the supervisor exists for, for real: rank 1 stops responding, rank 0 sits in an RCCL collective, the
-    ProcessGroupNCCL watchdog gives up after H2GCN_DIST_TIMEOUT_S and takes rank 0's process down -- not a Python exception.
-    One line on stdout all the same, measured by the relaunch, with the calibration the first attempt had completed."""
+    """The failure the supervisor exists for, for real: rank 1 stops responding (never returns from the diagnostics' exchange_only
+    stage), rank 0 sits in an RCCL collective, the ProcessGroupNCCL watchdog gives up after H2GCN_DIST_TIMEOUT_S and takes rank 0's
+    process down -- not a Python exception.  One line on stdout all the same, measured by the relaunch, with the calibration the
+    first attempt had completed.  (THE hung-rank test of the GPU suite: its gloo twin -- peers bounded by the attempt's wall-clock
+    budget or by the exchange's own bounded wait, a race between two legitimate outcomes -- is pinned with scripted workers in
+    tests/test_bench_supervisor.py::test_a_rank_that_hangs_is_bounded_by_the_attempt_budget.)  Asserted are EVENTS, not durations:
+    who died of what, what was on record, what the relaunch delivered."""
     lines, err, rcs = _run_supervised(2, ["--chunks", "2"], {"H2GCN_DIST_BACKEND": "nccl", "H2GCN_BENCH_HANG_RANK": "1",
-                                                             "H2GCN_BENCH_FAIL_STAGE": "exchange_only", "H2GCN_DIST_TIMEOUT_S": "25",
+                                                             "H2GCN_BENCH_FAIL_STAGE": "exchange_only", "H2GCN_DIST_TIMEOUT_S": "12",
+                                                             # the heartbeat monitor is what ends a watchdog whose ncclCommAbort
+                                                             # cannot complete (bench.py's default: time-out + 60 s)
+                                                             "TORCH_NCCL_HEARTBEAT_TIMEOUT_SEC": "20",
                                                              "H2GCN_BENCH_ATTEMPT_BUDGET_S": "240"})
     if os.environ.get("H2GCN_TEST_ARTIFACTS"):
         Path(os.environ["H2GCN_TEST_ARTIFACTS"]).mkdir(parents=True, exist_ok=True)
@@ -888,10 +870,13 @@ def test_bench_survives_a_real_rccl_watchdog_abort(tmp_path):
     assert len(lines) == 1 and rcs == [0, 0], (lines, err[-3000:])
     out = json.loads(lines[0])
     assert out["value"] > 0 and out["config"]["checksum_matches_n1"] is True and out["config"]["dist_backend"] == "nccl"
-    first = out["config"]["diagnostics"]["first_attempt"]
-    assert first["ranks"]["0"].startswith("killed by SIG"), first                  # the watchdog's abort, not an exit code
-    assert "budget" not in (first["first_failure"] or ""), first                   # ... long before the attempt's budget
-    assert len([e for e in first["calibration"] if "ms_per_step" in e]) == 2
+    diag = out["config"]["diagnostics"]
+    first = diag["first_attempt"]
+    assert first["attempt"] == 0 and first["ranks"]["0"].startswith("killed by SIG"), first   # the watchdog's abort, not an exit code
+    assert first["ranks"]["1"] != "ok", first                                                  # the hung rank never finished
+    assert "budget" not in (first["first_failure"] or ""), first                               # ... and not the attempt's budget
+    assert len([e for e in first["calibration"] if "ms_per_step" in e]) == 2                   # the stage before the hang is on record
+    assert diag["attempts"][0]["result"] != "ok" and diag["attempts"][-1]["result"] == "ok", diag["attempts"]
     _keep("bench_shared_gpu_rccl_watchdog_abort_n2.json", out)
 
 

@@ -161,11 +161,45 @@ def forward_vs_adjoint(a):
         configs.append(("F2 nostore (sums computed, no output stream)", lambda: pn.forward(x, y), b_alg((0, 1), 0)))
         configs.append(("F1 nostore", lambda: pn.forward(x, y1, mask=1), b_alg((0,), 0)))
         configs.append(("A2 nostore", lambda: pn.adjoint(dy, dx), b_alg((0, 1), 0)))
-    for label, kw in (("F2 variant 2 (index prefetch across segments)", dict(variant=2)), ("F2 rows_per_wave 1", dict(rows_per_wave=1)),
+    for label, kw in () if a.lite else (("F2 variant 2 (index prefetch across segments)", dict(variant=2)), ("F2 rows_per_wave 1", dict(rows_per_wave=1)),
                       ("F2 rows_per_wave 2", dict(rows_per_wave=2)), ("F2 rows_per_wave 7", dict(rows_per_wave=7)),
                       ("F2 slice 128", dict(slice_cols=128))):
         pv = plan(base, False, **kw)
         configs.append((label, (lambda q: (lambda: q.forward(x, y)))(pv), b_alg((0, 1), 2)))
+    if a.transposed:
+        # the same launches on the TRANSPOSED hop matrices: rows of A^T have Poisson(50) lengths (A's columns are uniform) and the
+        # gathered rows have A's Pareto row degrees as their popularity -- the forward on A^T reads like the adjoint on A and vice versa
+        def transpose(c):
+            rp, ci, va = c
+            counts = rp[1:] - rp[:-1]
+            rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), counts)
+            key = ci.to(torch.int64) * n + rows
+            del rows
+            key, order = torch.sort(key)
+            col_t = (key % n).to(torch.int32)
+            row_t = torch.div(key, n, rounding_mode="floor")
+            del key
+            rp_t = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            rp_t[1:] = torch.cumsum(torch.bincount(row_t, minlength=n), 0)
+            del row_t
+            va_t = va[order].contiguous()
+            return rp_t, col_t.contiguous(), va_t
+        csr_t = [transpose(c) for c in csr]
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        lt = Lib(base + "_T", libs[base])
+        lt.create(csr_t, n, transpose=True)
+        plans[("T",)] = lt
+        nnz_t = [int(c[0][-1]) for c in csr_t]
+        assert nnz_t == nnz
+        configs.append(("F2 forward on A^T (Poisson rows, Pareto-popular gathers)", lambda: lt.forward(x, y), b_alg((0, 1), 2)))
+        configs.append(("A2 adjoint on A^T (= SUM walk over A's Pareto rows)", lambda: lt.adjoint(dy, dx), b_alg((0, 1), 1)))
+        if "nostore" in libs:
+            ltn = Lib("nostore_T", libs["nostore"])
+            ltn.create(csr_t, n, transpose=True)
+            plans[("Tn",)] = ltn
+            configs.append(("F2 nostore on A^T", lambda: ltn.forward(x, y), b_alg((0, 1), 0)))
+            configs.append(("A2 nostore on A^T", lambda: ltn.adjoint(dy, dx), b_alg((0, 1), 0)))
     for name in libs:
         if name in (base, "nostore"):
             continue
@@ -196,6 +230,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--launches", type=int, default=10)
     ap.add_argument("--baseline", default=None, help="library the relative differences are quoted against (default: the second)")
+    ap.add_argument("--transposed", action="store_true", help="--matrix: also run forward / adjoint on the transposed hop matrices")
+    ap.add_argument("--lite", action="store_true", help="--matrix without the plan-option configurations (builds only)")
     ap.add_argument("--matrix", action="store_true", help="forward-vs-adjoint matrix on the first of --shapes (see forward_vs_adjoint)")
     a = ap.parse_args()
     if a.matrix:

@@ -11,6 +11,8 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+using f4v = float __attribute__((ext_vector_type(4)));
+
 __device__ inline unsigned long long mix(unsigned long long z) {
     z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
 }
@@ -52,7 +54,6 @@ __global__ __launch_bounds__(256) void copy_kernel(const float4* __restrict__ sr
                                     reinterpret_cast<float __attribute__((ext_vector_type(4)))*>(dst) + i);
 }
 
-using f4v = float __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void read_kernel(const f4v* __restrict__ src, size_t n, float* sink) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,6 +100,84 @@ double run_copy(size_t bytes) {
     return 2.0 * bytes * reps / (ms * 1e-3) / 1e9;
 }
 
+// ---- `gather_probe --mixed <table_MiB>` (round 6): what does an OUTPUT stream of ~2 % of the bytes cost a saturated random-gather
+// stream, and does it matter how the writes are bunched?  Every wave gathers `seg` random 256-byte rows per "segment" (8 loads in
+// flight, like the SpMM's wave walk) and owes 256 B of output per segment; it pays after every `bunch` segments with ONE contiguous
+// non-temporal write of bunch x 256 B (bunch = 0: never writes).  Neighbouring waves own neighbouring output regions.
+template <int BUNCH>
+__global__ __launch_bounds__(256) void mixed_kernel(const float4* __restrict__ table, long n_rows, int segments, int seg, float4* out) {
+    constexpr int LPR = 16, G = 4;
+    const int lane = threadIdx.x & 63, g = lane / LPR, li = lane % LPR;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float4* my_out = out + wave * (long)segments * LPR;          // segments x 256 B, contiguous per wave
+    float4 held = make_float4(0, 0, 0, 0);                       // BUNCH <= 4: lane group g holds the piece of segment (s % BUNCH) == g
+    for (int s = 0; s < segments; ++s) {
+        float4 acc = make_float4(0, 0, 0, 0);
+        for (int t = 0; t < seg; t += 8 * G) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned long long r = mix(((unsigned long long)wave * 4099ull + s) * 1000003ull + t + u * G + g) % (unsigned long long)n_rows;
+                x[u] = table[r * LPR + li];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+        }
+        // fold the 4 lane groups (every group ends up with the segment's piece)
+        acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+        acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+        if constexpr (BUNCH == 1) {
+            if (g == 0) __builtin_nontemporal_store(*reinterpret_cast<f4v*>(&acc), reinterpret_cast<f4v*>(my_out + (long)s * LPR) + li);
+        } else if constexpr (BUNCH == 4) {
+            if (g == (s & 3)) held = acc;
+            if ((s & 3) == 3)      // 64 lanes x 16 B = 1 KiB contiguous: the pieces of segments s-3 .. s
+                __builtin_nontemporal_store(*reinterpret_cast<f4v*>(&held), reinterpret_cast<f4v*>(my_out + (long)(s - 3) * LPR) + lane);
+        } else if constexpr (BUNCH == 16) {
+            __shared__ float4 stage[4][16][16];
+            if (g == 0) stage[threadIdx.x >> 6][s & 15][li] = acc;
+            if ((s & 15) == 15) {  // 4 x 1 KiB = 4 KiB contiguous
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 v = stage[threadIdx.x >> 6][k * 4 + g][li];
+                    __builtin_nontemporal_store(*reinterpret_cast<const f4v*>(&v), reinterpret_cast<f4v*>(my_out + (long)(s - 15 + k * 4) * LPR) + lane);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            if (acc.x == 12345.678f) my_out[li] = acc;   // never true; keeps the arithmetic alive
+        }
+    }
+}
+
+template <int BUNCH>
+double run_mixed(const float4* table, long n_rows, long n_waves, int segments, int seg, float4* out) {
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(mixed_kernel<BUNCH>, dim3(n_waves / 4), dim3(256), 0, 0, table, n_rows, segments, seg, out);
+    CHECK(hipEventRecord(a));
+    const int reps = 3;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(mixed_kernel<BUNCH>, dim3(n_waves / 4), dim3(256), 0, 0, table, n_rows, segments, seg, out);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    return (double)n_waves * segments * seg * 256.0 * reps / (ms * 1e-3) / 1e9;    // GATHERED bytes per second
+}
+
+int mixed(size_t table_mib) {
+    const size_t bytes = table_mib << 20;
+    float4* table; CHECK(hipMalloc(&table, bytes)); CHECK(hipMemset(table, 0, bytes));
+    const long n_waves = 1 << 17; const int segments = 256, seg = 64;       // 64 gathers of 256 B per 256 B written: 1.6 % writes
+    float4* out; CHECK(hipMalloc(&out, (size_t)n_waves * segments * 256));  // 8 GiB of output
+    printf("# random 256-B gathers out of %zu MiB, %ld waves x %d segments x %d gathers; 256 B owed per segment (%.1f %% of the bytes)\n",
+           table_mib, n_waves, segments, seg, 100.0 / seg);
+    for (int rep = 0; rep < 2; ++rep) {
+        printf("round %d: no writes %.0f GB/s | 256 B per segment %.0f | 1 KiB per 4 segments %.0f | 4 KiB per 16 segments %.0f\n", rep,
+               run_mixed<0>(table, bytes / 256, n_waves, segments, seg, out), run_mixed<1>(table, bytes / 256, n_waves, segments, seg, out),
+               run_mixed<4>(table, bytes / 256, n_waves, segments, seg, out), run_mixed<16>(table, bytes / 256, n_waves, segments, seg, out));
+    }
+    CHECK(hipFree(table)); CHECK(hipFree(out));
+    return 0;
+}
+
 // `gather_probe --point <table_MiB> <row_bytes>`: one gather point + the copy ceiling, as one JSON line (bench.py)
 int point(size_t table_mib, int row_bytes) {
     const size_t bytes = table_mib << 20;
@@ -128,6 +207,7 @@ int point(size_t table_mib, int row_bytes) {
 
 int main(int argc, char** argv) {
     if (argc == 4 && !strcmp(argv[1], "--point")) return point((size_t)atol(argv[2]), atoi(argv[3]));
+    if (argc == 3 && !strcmp(argv[1], "--mixed")) return mixed((size_t)atol(argv[2]));
     const size_t max_bytes = 8ull << 30;
     float4* table; CHECK(hipMalloc(&table, max_bytes)); CHECK(hipMemset(table, 0, max_bytes));
     const long n_waves = 1 << 18; const int gpw = 512;
