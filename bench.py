@@ -37,6 +37,11 @@ N1_CHECKSUMS = {("products", 128): -26948829970322352, ("products", 64): -133192
                 ("h2gcn_like", 128): -20343064339982979, ("products_tail", 128): -25034865256373447,
                 ("lowdeg", 128): -57806506298044835, ("hbm16m", 128): -132311004237956237, ("products_x6", 128): -179026745709730822}
 
+#: ... and of the adjoint dX = sum_k A_k^T W[:, k, :] with W = synth_features(2 d, seed 77) (`python -m oracle.fullsize --adjoint <shape>`:
+#: host-built transpose, the documented tree in plain C); single-GPU lines report `adjoint.checksum_matches_oracle`
+N1_ADJOINT_CHECKSUMS = {("arxiv", 128): -621262802795563, ("products", 128): -12144664314681507, ("lowdeg", 128): -25634735670479872,
+                        ("h2gcn_like", 128): -8224933467863159, ("products_tail", 128): -10435508044493920}
+
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
 
 
@@ -281,6 +286,7 @@ def hbm_resident_leg(timeout_s=600):
                 "frac_range": [b_alg / (rf["kernel_ms_max"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, b_alg / (rf["kernel_ms_min"] * 1e-3) / 1e9 / HBM_PEAK_GBPS],
                 "gather_ceiling_GBps": ceil, "stream_read_GBps": (rf.get("ceilings") or {}).get("stream_read_GBps"),
                 "achieved_over_gather_ceiling": None if not ceil else achieved / ceil,
+                "checksum_matches_oracle": c["config"].get("checksum_matches_n1"),   # Y of the 16M-row launch == the CPU oracle's, bit for bit
                 "source": f"LIVE child run of `bench.py --shape products_x6 --steps {HBM_LEG_STEPS} --warmup 2` on this box, same kernel and "
                           "schedule rule; figures from the MEDIAN launch; X and each of its column slices are >= 16x the Infinity "
                           "Cache, so this rate is DRAM-side"}
@@ -883,6 +889,7 @@ def main():
     want = N1_CHECKSUMS.get((a.shape, d))
     out["config"]["n1_checksum_expected"] = want
     out["config"]["checksum_matches_n1"] = None if want is None else (y_checksum == want)
+    out["config"]["checksum_source"] = "CPU oracle (oracle/fullsize.py: every row of the operands rebuilt on the host, documented summation tree in plain C)"
     if not a.no_adjoint:
         # backward launch dX = sum_k A_k^T dY[:, k, :] on the local shard: half of every training step
         # (reference h2gcn/models/H2GCN.py:66-74); secondary figure, not part of the metric
@@ -897,7 +904,13 @@ def main():
         torch.cuda.synchronize()
         adj = np.array([s_.elapsed_time(e_) for s_, e_ in evs])
         b_adj = sum(z * (4 + 4 + 4 * d) + (n + 1) * 8 for z in nnz_local) + n * d * 4
-        out["adjoint"] = {"kernel": "h2gcn::spmm_hops_kernel SUM mode on plan-owned A_k^T (local shard)",
+        adj_ck = None
+        if world == 1:      # (row-partitioned: dX is a per-rank partial before the reduce-scatter -- not comparable)
+            adj_ck = int(plan.spmm_t(dy).view(torch.int32).to(torch.int64).sum().item())
+        want_adj = N1_ADJOINT_CHECKSUMS.get((a.shape, d))
+        out["adjoint"] = {"checksum": adj_ck, "checksum_expected_from_oracle": want_adj,
+                          "checksum_matches_oracle": None if (adj_ck is None or want_adj is None) else adj_ck == want_adj,
+                          "kernel": "h2gcn::spmm_hops_kernel SUM mode on plan-owned A_k^T (local shard)",
                           "kernel_ms": float(adj.mean()), "kernel_ms_median": float(np.median(adj)),
                           "algorithmic_bytes_per_launch": b_adj,
                           "achieved_GBps": b_adj / (adj.mean() * 1e-3) / 1e9,
@@ -923,6 +936,7 @@ def main():
         out["roofline"]["hbm_resident_kernel_ms_min"] = leg.get("kernel_ms_min")
         out["roofline"]["hbm_resident_kernel_ms_max"] = leg.get("kernel_ms_max")
         out["roofline"]["hbm_resident_steps"] = leg.get("steps")
+        out["roofline"]["hbm_resident_checksum_matches_oracle"] = leg.get("checksum_matches_oracle")
     if (rank == 0 and world == 1 and a.shape == "products" and not (a.no_secondary or a.no_hbm_leg) and os.environ.get("H2GCN_BENCH_CHILD") != "1"
             and not any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ)):
         leg2 = secondary_leg("arxiv")

@@ -144,12 +144,32 @@ def oracle_checksum(shape, d=None, block_rows=2_000_000):
     return total, nnz
 
 
+def oracle_adjoint_checksum(shape, d=None, w_seed=77):
+    """Checksum of the oracle's dX = sum_k A_k^T W[:, k, :] for a whole shape (W = the counter-based features of seed 77, as bench.py's
+    adjoint leg uses them), in the library's documented order on a host-built transpose (scipy: stable counting sort)."""
+    import scipy.sparse as sp
+
+    parts, _, n, d = host_operands(shape, d)
+    w = synth_features_c(2 * d, w_seed, 0, n).reshape(n, 2, d)
+    t_parts = []
+    for rp, ci, va in parts:
+        t = sp.csr_matrix((va, ci, rp), shape=(n, n)).T.tocsr()
+        t.sort_indices()
+        t_parts.append((t.indptr.astype(np.int64), t.indices.astype(np.int32), t.data.astype(np.float32)))
+    del parts
+    return bits_checksum(gcn_layer_grad_tree_mt(t_parts, w))
+
+
 if __name__ == "__main__":
     import sys
     import time
 
-    for name in sys.argv[1:] or ["arxiv", "products"]:
+    args = [a_ for a_ in sys.argv[1:] if a_ != "--adjoint"]
+    for name in args or ["arxiv", "products"]:
         shape, _, dd = name.partition(":")
         t = time.time()
+        if "--adjoint" in sys.argv:
+            print(f'adjoint ("{shape}", {int(dd) if dd else "default d"}): {oracle_adjoint_checksum(shape, int(dd) if dd else None)}   [{time.time() - t:.1f} s]', flush=True)
+            continue
         ck, nnz = oracle_checksum(shape, int(dd) if dd else None)
         print(f'("{shape}", {int(dd) if dd else "default d"}): {ck}   nnz per hop {nnz}   [{time.time() - t:.1f} s]', flush=True)

@@ -10,8 +10,9 @@ the operands and every element of Y -- against the CPU oracle, at full size.
 * the order-independent checksum of the ORACLE's Y is what bench.py's N1_CHECKSUMS table holds for the shape (`python -m
   oracle.fullsize` prints it, CPU only): the `checksum_matches_n1` of every bench line is a comparison with the oracle, not with
   an earlier run of the HIP path;
-* adjoint: dX of the SUM-mode launch on the device-built transposed operands, bit-equal to the tree oracle on a host-built
-  transpose and within 2e-5 of the reference-order gradient bound (arxiv: every element; products: every element of the tree)."""
+* adjoint: every element of dX of the SUM-mode launch on the device-built transposed operands, bit-equal to the tree oracle on a
+  host-built transpose (its checksum is bench.py's N1_ADJOINT_CHECKSUMS entry); the identity <A x, w> == <x, A^T w> ties it to the
+  forward that has just been pinned to the reference's order."""
 import sys
 from pathlib import Path
 
@@ -93,6 +94,7 @@ def test_every_row_of_the_baseline_shape_against_the_oracle(shape):
     dx_tree = fs.gcn_layer_grad_tree_mt(t_parts, w_host)
     bad, first = fs.count_bit_mismatches(dx_hip, dx_tree)
     assert bad == 0, f"{shape} adjoint: {bad} of {dx_hip.size} elements differ from the canonical tree, first at flat index {first}"
+    assert fs.bits_checksum(dx_tree) == bench.N1_ADJOINT_CHECKSUMS[(shape, d)]      # what bench.py's adjoint leg is compared with
     # ... and the identity <A x, w> == <x, A^T w> ties the adjoint to the forward that (3) has pinned to the reference order
     lhs = float((y.double() * w.double()).sum().item())
     rhs = float((x.double() * dx.double()).sum().item())

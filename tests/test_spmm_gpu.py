@@ -1142,6 +1142,14 @@ def test_baseline_shapes_properties(shape):
                             "h2gcn_like": "lane group per segment (binned", "products_tail": "lane group per segment (binned"}.get(shape, "wave per segment")), walk
     x = synth.synth_features(d, synth.SEED_X, 0, n, device)
     y = plan.spmm(x)
+    # (0) every element, through the order-independent fingerprint: the checksum of Y is the CPU ORACLE's for this shape (computed by
+    #     `python -m oracle.fullsize`, profiles/r06_oracle_checksums_of_the_bench_shapes.txt; arxiv / products are also compared
+    #     element by element in tests/test_fullsize_parity_gpu.py)
+    import sys
+    from pathlib import Path as _P
+    sys.path.insert(0, str(_P(__file__).resolve().parents[1]))
+    import bench
+    assert int(y.view(torch.int32).to(torch.int64).sum().item()) == bench.N1_CHECKSUMS[(shape, d)]
     # (1) row-stochastic
     ones = torch.ones((n, d), device=device)
     y1 = plan.spmm(ones)
@@ -1157,6 +1165,7 @@ def test_baseline_shapes_properties(shape):
     plan_t = HopPlan([c[0] for c in csr], [c[1] for c in csr], [c[2] for c in csr], n, build_transpose=True)
     w = synth.synth_features(2 * d, 77, 0, n, device).view(n, 2, d)
     dx = plan_t.spmm_t(w)
+    assert int(dx.view(torch.int32).to(torch.int64).sum().item()) == bench.N1_ADJOINT_CHECKSUMS[(shape, d)]     # the oracle's dX, likewise
     lhs = (y.double() * w.double()).sum().item()
     rhs = (x.double() * dx.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs), (y.double().abs() * w.double().abs()).sum().item() * 1e-3)
