@@ -314,8 +314,8 @@ def test_row_partitioned_propagation_reuse_is_invisible(tmp_path):
     # also: the cross-round schedule of the sharded propagation (round k+1's exchange started per (chunk, hop) launch of
     # round k) against the round-by-round one, and the other exchange form
     configs = {"default": ("", {}, "ipc_engine"), "no_reuse": ("--no_propagation_reuse", {}, "ipc_engine"),
-               "round_by_round": ("--no_propagation_reuse", {"H2GCN_CROSS_ROUND": "0"}, "ipc_engine"),
-               "allgather": ("--no_propagation_reuse", {}, "allgather")}
+               "round_by_round": ("--no_propagation_reuse", {"H2GCN_CROSS_ROUND": "0"}, "ipc_engine")}
+    # (the other exchange form ends in the same statistics: test_ipc_exchange_is_verified_against_an_all_gather_and_falls_back)
     for name, (extra, more_env, exchange) in configs.items():
         port = _free_port()
         out_file = tmp_path / f"stats_{name}.json"
@@ -330,7 +330,7 @@ def test_row_partitioned_propagation_reuse_is_invisible(tmp_path):
         outs = [p.communicate(timeout=900)[0].decode() for p in procs]
         assert all(p.returncode == 0 for p in procs), "\n".join(outs)
         results[name] = json.loads(out_file.read_text())
-    for name in ("no_reuse", "round_by_round", "allgather"):
+    for name in ("no_reuse", "round_by_round"):
         for k in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_accuracy"):
             assert results["default"][k] == results[name][k], (name, k, results["default"][k], results[name][k])
 
@@ -614,7 +614,8 @@ def test_bench_multi_rank_branch_runs_and_matches_one_rank(tmp_path, world):
     # in test_bench_eight_ranks_on_one_gpu); N = 3 (170 000 rows / 3: a short last block) over gloo, without its slow stand-in for
     # the grouped send/recv form.  "Matches one rank": the line's checksum equals the ORACLE's for the shape (bench.N1_CHECKSUMS,
     # recomputed on the CPU in tests/test_oracle_tree_and_classifier.py) -- and so do 1-rank runs with other chunkings / slice widths
-    extra_env = {"H2GCN_BENCH_EXCHANGES": "allgather,ipc_engine,ipc_kernel"} if world == 3 else {"H2GCN_DIST_BACKEND": "nccl"}
+    extra_env = ({"H2GCN_BENCH_EXCHANGES": "allgather,ipc_engine,ipc_kernel", "H2GCN_BENCH_CHUNK_SPECS": "1,2"} if world == 3
+                 else {"H2GCN_DIST_BACKEND": "nccl"})
     out = _run_bench(world, ["--shape", "arxiv", "--steps", "3", "--warmup", "1"], tmp_path, env_extra=extra_env)
     assert out["n_gpus"] == world and out["value"] > 0 and out["roofline"]["kernel_ms_max_over_ranks"] > 0
     assert out["config"]["dist_backend"] == ("gloo" if world == 3 else "nccl")
@@ -859,10 +860,10 @@ def test_bench_survives_a_real_rccl_watchdog_abort(tmp_path):
     tests/test_bench_supervisor.py::test_a_rank_that_hangs_is_bounded_by_the_attempt_budget.)  Asserted are EVENTS, not durations:
     who died of what, what was on record, what the relaunch delivered."""
     lines, err, rcs = _run_supervised(2, ["--chunks", "2"], {"H2GCN_DIST_BACKEND": "nccl", "H2GCN_BENCH_HANG_RANK": "1",
-                                                             "H2GCN_BENCH_FAIL_STAGE": "exchange_only", "H2GCN_DIST_TIMEOUT_S": "12",
+                                                             "H2GCN_BENCH_FAIL_STAGE": "exchange_only", "H2GCN_DIST_TIMEOUT_S": "10",
                                                              # the heartbeat monitor is what ends a watchdog whose ncclCommAbort
                                                              # cannot complete (bench.py's default: time-out + 60 s)
-                                                             "TORCH_NCCL_HEARTBEAT_TIMEOUT_SEC": "20",
+                                                             "TORCH_NCCL_HEARTBEAT_TIMEOUT_SEC": "15",
                                                              "H2GCN_BENCH_ATTEMPT_BUDGET_S": "240"})
     if os.environ.get("H2GCN_TEST_ARTIFACTS"):
         Path(os.environ["H2GCN_TEST_ARTIFACTS"]).mkdir(parents=True, exist_ok=True)
