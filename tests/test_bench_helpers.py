@@ -108,3 +108,22 @@ def test_rccl_log_summary_on_the_format_rccl_2_26_writes(tmp_path):
     assert len(got) <= 10 and got[0].startswith("RCCL version") and "Init COMPLETE" in got[1] and "coll channels" in got[2]
     assert sum("Pattern" in g for g in got) == 2
     assert sum("Could not read node" in g for g in got) == 1 and sum("iommu" in g for g in got) == 1
+
+
+def test_peak_source_reads_the_box_and_says_whether_it_confirms_the_constant():
+    """`roofline.peak_source` ("confirm on the box"): memory clock x bus width as tools/gather_probe reports them from
+    hipDeviceProp_t -> the rate at 4 transfers per reported clock, compared with the 8 TB/s spec constant the fractions are quoted on."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+
+    ok = bench.peak_source({"memory_clock_khz": 2000000, "memory_bus_width_bits": 8192, "device_name": "x", "gcn_arch": "gfx950"})
+    assert ok["peak_confirmed_on_box"] is True and abs(ok["peak_box_derived_GBps"] - 8192.0) < 1e-6 and "confirms the constant" in ok["peak_source"]
+    mi300 = bench.peak_source({"memory_clock_khz": 1300000, "memory_bus_width_bits": 8192})      # another part: 5.3 TB/s, not this constant
+    assert mi300["peak_confirmed_on_box"] is False and abs(mi300["peak_box_derived_GBps"] - 5324.8) < 1e-6 and "does NOT match" in mi300["peak_source"]
+    for missing in (None, {}, {"error": "tools/gather_probe not built"}, {"memory_clock_khz": 0, "memory_bus_width_bits": 8192}):
+        none = bench.peak_source(missing)
+        assert none["peak_confirmed_on_box"] is False and "reported no memory clock" in none["peak_source"]
+    assert set(bench.N1_ADJOINT_CHECKSUMS) <= set(bench.N1_CHECKSUMS)       # every adjoint constant belongs to a shape with a forward one
