@@ -662,6 +662,7 @@ def test_bench_two_ranks_products_shape(tmp_path):
     for ex in ("allgather", "ipc_engine"):
         out = _run_bench(2, ["--steps", "2", "--warmup", "1", "--exchange", ex, "--chunks", "2", "--no-adjoint"], tmp_path)
         assert out["value"] > 0 and out["config"]["diagnostics"]["exchange"] == ex
+        assert out["config"]["checksum_matches_n1"] is True      # 2 ranks, full products shape: Y == the CPU oracle's, all 2.4M rows
         sums[ex] = out["config"]["y_checksum"]
         _keep(f"bench_shared_gpu_products_n2_{ex}.json", out)
     assert sums["allgather"] == sums["ipc_engine"]
