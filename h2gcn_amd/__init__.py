@@ -25,7 +25,7 @@ any slicing, chunking or row partition gives the same bits.
 There is no CPU fallback: every compute entry point raises if the HIP library or a GPU is missing.
 """
 
-__version__ = "0.5.0"
+__version__ = "0.6.0"
 
 from . import _capi  # noqa: F401  (does not load the library until first use)
 from .hops import HopPlan  # noqa: F401
