@@ -37,7 +37,7 @@ _DEFAULT_CAP_S = 420
 
 def _order_key(item):
     stem = Path(str(item.fspath)).stem
-    rank = _FILE_RANK.index(stem) if stem in _FILE_RANK else len(_FILE_RANK) - 1      # unknown files: before the multi-process file
+    rank = _FILE_RANK.index(stem) if stem in _FILE_RANK else len(_FILE_RANK) - 1.5    # unknown files: just before the multi-process file
     late = 1 if (stem == "test_multirank_gpu" and (item.name.startswith("test_bench_") or item.name.startswith("test_rccl_"))) else 0
     return (rank, late)
 
