@@ -178,6 +178,59 @@ int mixed(size_t table_mib) {
     return 0;
 }
 
+// ---- `gather_probe --short <table_MiB>` (round 6): the ceiling of the SHORT-ROW regimes (lowdeg: ~4 neighbours per segment, hbm16m: ~8):
+// every LANE GROUP owns a stream of output pieces; per piece it gathers K random rows of LPR*16 bytes (8 loads in flight per lane,
+// i.e. 8/K pieces per batch), sums them and writes one piece of the same width (non-temporal).  Bytes counted: gathered + written.
+template <int LPR, int K>
+__global__ __launch_bounds__(256) void short_kernel(const float4* __restrict__ table, long n_rows, int batches, float4* out) {
+    constexpr int G = 64 / LPR, P = 8 / K;       // lane groups per wave, pieces per batch and group
+    const int lane = threadIdx.x & 63, g = lane / LPR, li = lane % LPR;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float4* my_out = out + ((wave * G + g) * (long)batches * P) * LPR;      // this group's pieces, contiguous
+    for (int b = 0; b < batches; ++b) {
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long r = mix(((unsigned long long)(wave * G + g) * 4099ull + b) * 1000003ull + u) % (unsigned long long)n_rows;
+            x[u] = table[r * LPR + li];
+        }
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < K; ++u) { acc.x += x[q * K + u].x; acc.y += x[q * K + u].y; acc.z += x[q * K + u].z; acc.w += x[q * K + u].w; }
+            __builtin_nontemporal_store(*reinterpret_cast<f4v*>(&acc), reinterpret_cast<f4v*>(my_out + ((long)b * P + q) * LPR) + li);
+        }
+    }
+}
+
+template <int LPR, int K>
+double run_short(const float4* table, long n_rows, long n_waves, int batches, float4* out) {
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL((short_kernel<LPR, K>), dim3(n_waves / 4), dim3(256), 0, 0, table, n_rows, batches, out);
+    CHECK(hipEventRecord(a));
+    const int reps = 3;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((short_kernel<LPR, K>), dim3(n_waves / 4), dim3(256), 0, 0, table, n_rows, batches, out);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    const double gathered = (double)n_waves * 64 * 8.0 * batches * 16.0, written = gathered / K;
+    return (gathered + written) * reps / (ms * 1e-3) / 1e9;
+}
+
+int short_rows(size_t table_mib) {
+    const size_t bytes = table_mib << 20;
+    float4* table; CHECK(hipMalloc(&table, bytes)); CHECK(hipMemset(table, 0, bytes));
+    const long n_waves = 1 << 17; const int batches = 64;
+    float4* out; CHECK(hipMalloc(&out, (size_t)n_waves * 64 * 8 * batches * 16 / 4));   // K = 4: a quarter of the gathered bytes
+    printf("# short rows: every lane group gathers K random rows per output piece out of %zu MiB; gathered + written GB/s\n", table_mib);
+    for (int rep = 0; rep < 2; ++rep)
+        printf("round %d: 512-B rows K=4 (lowdeg d=128) %.0f GB/s | 512-B rows K=8 (hbm16m d=128) %.0f | 256-B rows K=4 (lowdeg d=64) %.0f | 256-B rows K=8 %.0f\n", rep,
+               run_short<32, 4>(table, bytes / 512, n_waves, batches, out), run_short<32, 8>(table, bytes / 512, n_waves, batches, out),
+               run_short<16, 4>(table, bytes / 256, n_waves, batches, out), run_short<16, 8>(table, bytes / 256, n_waves, batches, out));
+    CHECK(hipFree(table)); CHECK(hipFree(out));
+    return 0;
+}
+
 // `gather_probe --point <table_MiB> <row_bytes>`: one gather point + the copy ceiling, as one JSON line (bench.py)
 int point(size_t table_mib, int row_bytes) {
     const size_t bytes = table_mib << 20;
@@ -208,6 +261,7 @@ int point(size_t table_mib, int row_bytes) {
 int main(int argc, char** argv) {
     if (argc == 4 && !strcmp(argv[1], "--point")) return point((size_t)atol(argv[2]), atoi(argv[3]));
     if (argc == 3 && !strcmp(argv[1], "--mixed")) return mixed((size_t)atol(argv[2]));
+    if (argc == 3 && !strcmp(argv[1], "--short")) return short_rows((size_t)atol(argv[2]));
     const size_t max_bytes = 8ull << 30;
     float4* table; CHECK(hipMalloc(&table, max_bytes)); CHECK(hipMemset(table, 0, max_bytes));
     const long n_waves = 1 << 18; const int gpw = 512;
