@@ -181,16 +181,16 @@ int mixed(size_t table_mib) {
 // ---- `gather_probe --short <table_MiB>` (round 6): the ceiling of the SHORT-ROW regimes (lowdeg: ~4 neighbours per segment, hbm16m: ~8):
 // every LANE GROUP owns a stream of output pieces; per piece it gathers K random rows of LPR*16 bytes (8 loads in flight per lane,
 // i.e. 8/K pieces per batch), sums them and writes one piece of the same width (non-temporal).  Bytes counted: gathered + written.
-template <int LPR, int K>
+template <int LPR, int K, int U = 8>
 __global__ __launch_bounds__(256) void short_kernel(const float4* __restrict__ table, long n_rows, int batches, float4* out) {
-    constexpr int G = 64 / LPR, P = 8 / K;       // lane groups per wave, pieces per batch and group
+    constexpr int G = 64 / LPR, P = U / K;       // lane groups per wave, pieces per batch and group (U loads in flight per lane)
     const int lane = threadIdx.x & 63, g = lane / LPR, li = lane % LPR;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     float4* my_out = out + ((wave * G + g) * (long)batches * P) * LPR;      // this group's pieces, contiguous
     for (int b = 0; b < batches; ++b) {
-        float4 x[8];
+        float4 x[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < U; ++u) {
             const unsigned long long r = mix(((unsigned long long)(wave * G + g) * 4099ull + b) * 1000003ull + u) % (unsigned long long)n_rows;
             x[u] = table[r * LPR + li];
         }
@@ -204,16 +204,17 @@ __global__ __launch_bounds__(256) void short_kernel(const float4* __restrict__ t
     }
 }
 
-template <int LPR, int K>
+template <int LPR, int K, int U = 8>
 double run_short(const float4* table, long n_rows, long n_waves, int batches, float4* out) {
+    batches = batches * 8 / U;
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
-    hipLaunchKernelGGL((short_kernel<LPR, K>), dim3(n_waves / 4), dim3(256), 0, 0, table, n_rows, batches, out);
+    hipLaunchKernelGGL((short_kernel<LPR, K, U>), dim3(n_waves / 4), dim3(256), 0, 0, table, n_rows, batches, out);
     CHECK(hipEventRecord(a));
     const int reps = 3;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((short_kernel<LPR, K>), dim3(n_waves / 4), dim3(256), 0, 0, table, n_rows, batches, out);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((short_kernel<LPR, K, U>), dim3(n_waves / 4), dim3(256), 0, 0, table, n_rows, batches, out);
     CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
     float ms; CHECK(hipEventElapsedTime(&ms, a, b));
-    const double gathered = (double)n_waves * 64 * 8.0 * batches * 16.0, written = gathered / K;
+    const double gathered = (double)n_waves * 64 * (double)U * batches * 16.0, written = gathered / K;
     return (gathered + written) * reps / (ms * 1e-3) / 1e9;
 }
 
@@ -227,6 +228,10 @@ int short_rows(size_t table_mib) {
         printf("round %d: 512-B rows K=4 (lowdeg d=128) %.0f GB/s | 512-B rows K=8 (hbm16m d=128) %.0f | 256-B rows K=4 (lowdeg d=64) %.0f | 256-B rows K=8 %.0f\n", rep,
                run_short<32, 4>(table, bytes / 512, n_waves, batches, out), run_short<32, 8>(table, bytes / 512, n_waves, batches, out),
                run_short<16, 4>(table, bytes / 256, n_waves, batches, out), run_short<16, 8>(table, bytes / 256, n_waves, batches, out));
+    for (int rep = 0; rep < 2; ++rep)
+        printf("round %d, 16 loads in flight: 512-B rows K=4 %.0f GB/s | 512-B rows K=8 %.0f | 256-B rows K=4 %.0f | 4 loads in flight: 512-B rows K=4 %.0f\n", rep,
+               run_short<32, 4, 16>(table, bytes / 512, n_waves, batches, out), run_short<32, 8, 16>(table, bytes / 512, n_waves, batches, out),
+               run_short<16, 4, 16>(table, bytes / 256, n_waves, batches, out), run_short<32, 4, 4>(table, bytes / 512, n_waves, batches, out));
     CHECK(hipFree(table)); CHECK(hipFree(out));
     return 0;
 }
