@@ -13,6 +13,7 @@ the operands and every element of Y -- against the CPU oracle, at full size.
 * adjoint: every element of dX of the SUM-mode launch on the device-built transposed operands, bit-equal to the tree oracle on a
   host-built transpose (its checksum is bench.py's N1_ADJOINT_CHECKSUMS entry); the identity <A x, w> == <x, A^T w> ties it to the
   forward that has just been pinned to the reference's order."""
+import os
 import sys
 from pathlib import Path
 
@@ -37,7 +38,13 @@ def _device_operands(shape):
     return csr, x, n, d
 
 
-@pytest.mark.parametrize("shape", ["arxiv", "products"])
+#: the two BASELINE shapes always; H2GCN_FULLSIZE_ALL=1 adds the other benchmark shapes that have oracle checksums (the in-tile short-row
+#: walk and the list-driven walks at full size: +70 s; their checksums are asserted in every run by test_spmm_gpu.py
+#: ::test_baseline_shapes_properties, the element-wise run is on record in profiles/r06_fullsize_all_shapes.txt)
+_SHAPES = ["arxiv", "products"] + (["lowdeg", "h2gcn_like", "products_tail"] if os.environ.get("H2GCN_FULLSIZE_ALL") == "1" else [])
+
+
+@pytest.mark.parametrize("shape", _SHAPES)
 def test_every_row_of_the_baseline_shape_against_the_oracle(shape):
     from h2gcn_amd import HopPlan
     from oracle import fullsize as fs
